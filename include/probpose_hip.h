@@ -1,0 +1,150 @@
+/*
+ * probpose_hip.h -- C ABI of libprobpose_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the ProbPose forward + decode hot path.
+ * The reference (zir-vision/ProbPose_pytorch) has no FFI layer: its boundary
+ * is the Python class API (probpose.model / backbone / head / codec).  The
+ * Python host in probpose_pytorch_amd/ keeps that class API and binds these
+ * entry points with ctypes; every entry point below cites the reference
+ * interface (file:line, relative to the reference checkout) it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch types.  All device buffers are
+ *     caller-owned (torch tensors' data_ptr()); nothing is allocated here
+ *     except inside pp_engine_create (weights arena, freed by pp_engine_destroy).
+ *   - every launch takes an explicit hipStream_t (as void*); calls are
+ *     asynchronous and capturable into a hipGraph (no sync, no malloc).
+ *   - return value: 0 = ok, <0 = error; pp_last_error() gives the message
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - dtype enum: PP_F32 = 0 (fp32 storage, exact-fp32 MFMA), PP_BF16 = 1
+ *     (bf16 storage, bf16 MFMA, fp32 accumulate).
+ */
+#ifndef PROBPOSE_HIP_H
+#define PROBPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_F32 0
+#define PP_BF16 1
+
+#define PP_MAX_RADIUS 9                 /* heatmap.py:178-179: s<=3.0 -> ceil(3s)<=9 */
+#define PP_MAX_TAPS (2 * PP_MAX_RADIUS + 1)
+
+/* epilogue flags of pp_gemm (bit-or) */
+#define PP_EPI_BIAS 1                   /* + bias[n]                                  */
+#define PP_EPI_GELU 2                   /* exact-erf GELU (timm Mlp act)              */
+#define PP_EPI_RELU 4                   /* ReLU (head.py:120)                         */
+#define PP_EPI_RESIDUAL 8               /* out_f32 = residual_f32 + (acc + bias)      */
+#define PP_EPI_OUT_F32 16               /* store fp32 regardless of the storage dtype */
+#define PP_EPI_ROWBIAS 32               /* + rowbias[(m % rowbias_period) * ldc + n]  (pos_embed) */
+
+int pp_version(void);
+const char *pp_last_error(void);
+/* 1 when a gfx950 device is visible to this process, else 0 (never throws). */
+int pp_device_ok(void);
+
+/* ------------------------------------------------------------------------
+ * Fused decode.  Replaces, in one launch per batch:
+ *   Codec.decode            probpose/codec.py:249-263
+ *   ProbMap.decode          probpose/codec.py:214-239
+ *   get_heatmap_expected_value + _get_subpixel_maximums
+ *                           probpose/heatmap.py:291-395, :114-167
+ *   the D2H copy of util.to_numpy   probpose/util.py:6-12
+ * (OKS kernels of heatmap.py:170-194 arrive pre-factored as normalised 1-D
+ * taps; the 2-D kernel is exactly their outer product.)
+ *
+ * heatmaps [B,K,H,W] f32 contiguous.  prob/vis/oks/err: [B*K] f32 or NULL.
+ * taps [K][PP_MAX_TAPS] f64 (entry j = offset j - radius[k]), radius [K].
+ * den_x/den_y = heatmap_size-1 ([W-1,H-1] of codec.py:237), in_w/in_h = input_size.
+ * Outputs (each may be NULL): kpts f64 [B,K,2] (input-image space),
+ * scores f32 [B,K] (raw heatmap at the integer peak), locs f32 [B,K,2]
+ * (heatmap space, = get_heatmap_expected_value's locs), aux f32 [3,B,K]
+ * (prob,vis,oks passthrough), err f64 [B,K] (= err / sqrt(H^2+W^2)),
+ * conv f32 [B,K,H,W] (return_heatmap=True).
+ * workspace: pp_decode_workspace_bytes() bytes (0 when the map fits in LDS).
+ * ---------------------------------------------------------------------- */
+size_t pp_decode_workspace_bytes(int B, int K, int H, int W);
+int pp_decode_f32(const float *heatmaps, const float *prob, const float *vis,
+                  const float *oks, const float *err, int B, int K, int H, int W,
+                  const double *taps, const int *radius, double den_x, double den_y,
+                  double in_w, double in_h, double *out_kpts, float *out_scores,
+                  float *out_locs, float *out_aux, double *out_err, float *out_conv,
+                  void *workspace, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Dense contraction on MFMA:  C[M,N] = epilogue(A[M,Kd] * W[N,Kd]^T).
+ * Replaces torch.nn.Linear / Conv2d-as-GEMM call sites of the backbone
+ * (timm VisionTransformer via probpose/backbone.py:26-39: patch_embed.proj,
+ * attn.qkv, attn.proj, mlp.fc1, mlp.fc2) and of the head (head.py:227-233
+ * final_layer, :262-285 aux convs, :459-469 deconvs after im2col-free row
+ * gather).  A rows are addressed through an optional gather table so 3x3
+ * convolutions and the four stride-2 deconvolution parities run as implicit
+ * GEMMs with no im2col buffer:
+ *   A(m, k) = Abase[ rowoff[(k / seg_len) * M + m] + (k % seg_len) ]   (rowoff<0 -> 0)
+ * with rowoff == NULL meaning A(m,k) = Abase[m*lda + k].
+ * batch > 1 runs independent problems (strideA/W/C/bias in elements).
+ * dtype selects storage+MFMA type for A, W and (unless PP_EPI_OUT_F32) C.
+ * ---------------------------------------------------------------------- */
+typedef struct pp_gemm_args {
+  const void *A; const void *W; void *C;
+  const float *bias;            /* [N] f32 or NULL                      */
+  const float *residual;        /* [M,ldc] f32 (PP_EPI_RESIDUAL)        */
+  const float *rowbias;         /* [rowbias_period, ldc] f32            */
+  const int32_t *rowoff;        /* [segs*M] element offsets or NULL     */
+  int M, N, Kd;
+  int lda, ldw, ldc;
+  int seg_len;                  /* K-segment length for the gather      */
+  int rowbias_period;
+  int batch;
+  long long strideA, strideW, strideC, strideBias;
+  int dtype;                    /* PP_F32 | PP_BF16                     */
+  int epilogue;                 /* PP_EPI_* flags                       */
+} pp_gemm_args;
+int pp_gemm(const pp_gemm_args *args, void *stream);
+
+/* LayerNorm over the last dim (timm Block.norm1/norm2/final norm, eps 1e-6).
+ * x [rows,C] f32 (the fp32 residual stream) -> out [rows,C] in `dtype`. */
+int pp_layernorm(const float *x, const float *gamma, const float *beta, float eps,
+                 int rows, int C, void *out, int dtype, void *stream);
+
+/* Multi-head self-attention (timm Attention.forward: softmax(q k^T * hd^-1/2) v).
+ * qkv [B*N, 3*heads*hd] laid out [3][heads][hd] along the row (timm's
+ * reshape(B,N,3,heads,hd)); out [B*N, heads*hd]. */
+int pp_attention(const void *qkv, void *out, int B, int N, int heads, int hd,
+                 int dtype, void *stream);
+
+/* Patch im2col + cast: x [B,3,H,W] f32 NCHW -> A [B*gh*gw, 3*p*p] (k = c*p*p + py*p + px),
+ * the A operand of patch_embed.proj as a GEMM (timm PatchEmbed, stride = patch). */
+int pp_patchify(const float *x, void *out, int B, int H, int W, int patch, int dtype,
+                void *stream);
+
+/* MaxPool(kh,kw stride kh,kw) + ReLU on channels-last rows (head.py:271-276):
+ * x [B, h, w, C] -> out [B, h/kh, w/kw, C]. */
+int pp_maxpool_relu(const void *x, void *out, int B, int h, int w, int C, int kh, int kw,
+                    int dtype, void *stream);
+
+/* Final 1x1 conv + temperature + clamp, NHWC -> NCHW (head.py:525-532):
+ * x [B*HW, Cin] -> heatmaps [B,K,H*W] f32 = clamp((x*W^T + b) / temperature, 0, 1). */
+int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B,
+                     int HW, int Cin, int K, float inv_temperature, int dtype, void *stream);
+
+/* Aux tail: 1x1 conv C->K on pooled 1x1 features + Sigmoid/ReLU (head.py:277-286,:391-400).
+ * x [4 branches][B, C] -> out [4][B,K] f32 (branches 0..2 sigmoid, 3 relu). */
+int pp_aux_tail(const void *x, const void *w, const float *bias, float *out, int B, int C,
+                int K, int dtype, void *stream);
+
+/* (B,N,C) tokens -> (B,C,gh,gw) f32, the permute of backbone.py:40. */
+int pp_tokens_to_nchw(const void *x, float *out, int B, int N, int C, int dtype, void *stream);
+/* (B,C,h,w) f32 NCHW -> (B,h*w,C) channels-last rows in `dtype` (head entry when
+ * ProbMapHead.forward is called on a foreign NCHW feature map). */
+int pp_nchw_to_tokens(const float *x, void *out, int B, int C, int HW, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROBPOSE_HIP_H */

@@ -1,0 +1,100 @@
+"""Mirror of the hot-path part of the reference's ``probpose/codec.py``:
+``ProbMap`` (codec.py:73-239, decode side) and ``Codec`` (codec.py:242-267).
+
+``Codec.decode`` keeps the reference return structure but never copies the
+heatmaps to the host: one fused HIP launch decodes the whole batch on the
+device and only B*K*7 numbers cross PCIe.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .heatmap import decode_on_device
+from .util import to_numpy
+
+
+class ProbMap:
+    """Reference codec.py:117-136 (constructor) and :214-239 (decode).
+
+    ``input_size`` is [w, h], ``heatmap_size`` is [W, H]."""
+
+    def __init__(self, input_size, heatmap_size, sigmas, sigma: float = 2.0,
+                 radius_factor: float = 0.0546875, blur_kernel_size: int = 11,
+                 increase_sigma_with_padding=False) -> None:
+        self.input_size = input_size
+        self.heatmap_size = heatmap_size
+        self.radius_factor = radius_factor
+        self.blur_kernel_size = blur_kernel_size
+        self.scale_factor = ((np.array(input_size) - 1) / (np.array(heatmap_size) - 1)).astype(np.float32)
+        self.increase_sigma_with_padding = increase_sigma_with_padding
+        self.sigmas = sigmas
+        self.sigma = sigma
+
+    # -- device side ------------------------------------------------------
+    def decode_device(self, heatmaps: torch.Tensor, aux=None) -> dict:
+        """(B,K,H,W) device heatmaps -> dict of device tensors (kpts f64, scores f32, ...)."""
+        W, H = self.heatmap_size
+        return decode_on_device(heatmaps, self.sigmas, den=(W - 1, H - 1),
+                                input_size=self.input_size, aux=aux)
+
+    # -- reference surface ------------------------------------------------
+    def decode(self, encoded):
+        """(K,H,W) [or (B,K,H,W)] heatmaps -> keypoints (1,K,2) f64 [or (B,K,2)],
+        scores (1,K) f32 [or (B,K)].  Reference codec.py:214-239; the input is
+        never modified (the reference copies it, :228)."""
+        _lib.require_device()
+        t = torch.from_numpy(np.ascontiguousarray(encoded)) if isinstance(encoded, np.ndarray) else encoded
+        if t.ndim == 3:
+            t = t[None]
+        if t.ndim != 4:
+            raise AssertionError(f"Invalid shape {tuple(t.shape)}")
+        if not t.is_cuda:
+            t = t.cuda(non_blocking=True)
+        out = self.decode_device(t)
+        return out["kpts"].cpu().numpy(), out["scores"].cpu().numpy()
+
+    def encode(self, *args, **kwargs):
+        raise NotImplementedError(
+            "ProbMap.encode (training-target generation, reference codec.py:138-212) is outside "
+            "the forward+decode hot path built here")
+
+
+class Codec:
+    """Reference codec.py:242-267."""
+
+    def __init__(self, probmap):
+        self.probmap = probmap
+
+    def decode_device(self, pred) -> dict:
+        """Fused decode that leaves everything on the device (used by the
+        data-parallel all-gather): kpts (B,K,2) f64, scores (B,K) f32,
+        aux (3,B,K) f32 = prob/vis/oks, err (B,K) f64 (already / diagonal)."""
+        heatmaps, probabilities, visibilities, oks, errors = pred
+        _lib.require_device(heatmaps)
+        return self.probmap.decode_device(heatmaps, aux=(probabilities, visibilities, oks, errors))
+
+    def decode(self, pred):
+        """5-tuple (heatmaps, prob, vis, oks, err) -> ((kpts (B,K,2) f64, scores (B,K) f32),
+        prob (B,1,K) f32, vis, oks, err (B,1,K) f64).  Reference codec.py:249-263
+        (which only works for B == 1; B > 1 is the stack of per-crop results)."""
+        heatmaps = pred[0]
+        B, K = heatmaps.shape[0], heatmaps.shape[1]
+        pred = tuple(torch.from_numpy(np.ascontiguousarray(p)).cuda() if isinstance(p, np.ndarray)
+                     else p for p in pred)
+        out = self.decode_device(pred)
+        # one packed D2H instead of the reference's full-heatmap to_numpy (util.py:6-12)
+        kpts = out["kpts"].cpu().numpy()
+        scores = out["scores"].cpu().numpy()
+        aux = out["aux"].cpu().numpy()
+        err = out["err"].cpu().numpy()
+        return ((kpts, scores), aux[0].reshape(B, 1, K), aux[1].reshape(B, 1, K),
+                aux[2].reshape(B, 1, K), err.reshape(B, 1, K))
+
+    def decode_heatmap(self, heatmaps):
+        """Reference codec.py:265-267."""
+        return self.probmap.decode(heatmaps if isinstance(heatmaps, torch.Tensor) else to_numpy(heatmaps))
+
+    def encode(self, *args, **kwargs):
+        return self.probmap.encode(*args, **kwargs)

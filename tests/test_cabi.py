@@ -1,0 +1,56 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950,
+loads without a GPU and exports every symbol include/probpose_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "probpose_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from probpose_pytorch_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/probpose_hip.h but not exported"
+    # the Python binding covers the whole header too
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_version_and_error_string(built_lib):
+    assert built_lib.pp_version() >= 100
+    assert isinstance(built_lib.pp_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """Host-side checks run before any launch, so they can be exercised on CPU."""
+    from probpose_pytorch_amd import _lib
+    rc = built_lib.pp_decode_f32(None, None, None, None, None, 1, 17, 64, 48, None, None,
+                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None)
+    assert rc != 0 and b"null" in built_lib.pp_last_error()
+    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == 0
+    assert built_lib.pp_decode_workspace_bytes(1, 20, 256, 256) == 20 * 256 * 256 * 12
+    with pytest.raises(_lib.HipExtensionError):
+        _lib.check(rc, "pp_decode_f32")
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from probpose_pytorch_amd import Codec, ProbMap, _lib, get_heatmap_expected_value
+    hm = np.zeros((17, 64, 48), np.float32)
+    with pytest.raises(_lib.HipExtensionError):
+        get_heatmap_expected_value(hm, np.full(17, 0.05))
+    with pytest.raises(_lib.HipExtensionError):
+        Codec(ProbMap((192, 256), (48, 64), np.full(17, 0.05))).decode_heatmap(hm)

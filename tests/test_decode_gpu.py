@@ -1,0 +1,173 @@
+"""GPU parity tests of the fused decode (csrc/pp_decode.hip) through the
+Python mirror of the reference API, against (1) the goldens minted from the
+reference and (2) the CPU oracle on seeded inputs.
+
+Tolerances: integer work (argmax location, score gather) bit-exact; float32
+heatmap-space locs bit-exact (same float32 arithmetic on a bit-identical
+convolved map); float64 keypoints within 1e-4 px abs (north_star), observed 0.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import probpose_oracle as orc
+from tests.helpers import DECODE_FIXTURES, GOLDEN, load_decode_fixture
+
+pytestmark = pytest.mark.gpu
+
+ATOL_KPTS = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pp(built_lib):
+    import probpose_pytorch_amd as p
+    assert torch.cuda.is_available()
+    assert built_lib.pp_device_ok() == 1, "expected a gfx950 device"
+    return p
+
+
+def _dev(arrs):
+    return tuple(torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs)
+
+
+@pytest.mark.parametrize("name", DECODE_FIXTURES)
+def test_codec_decode_matches_reference_golden(pp, name):
+    g, hm, aux = load_decode_fixture(name)
+    codec = pp.Codec(pp.ProbMap(tuple(g["in_size"]), (int(g["W"]), int(g["H"])), g["sigmas"]))
+    (kpts, scores), prob, vis, oks, err = codec.decode(_dev((hm, *aux)))
+    assert kpts.dtype == np.float64 and scores.dtype == np.float32 and err.dtype == np.float64
+    assert kpts.shape == g["kpts"].shape and prob.shape == g["prob"].shape
+    np.testing.assert_allclose(kpts, g["kpts"], rtol=0, atol=ATOL_KPTS)
+    np.testing.assert_array_equal(scores, g["scores"])
+    np.testing.assert_array_equal(prob, g["prob"])
+    np.testing.assert_array_equal(vis, g["vis"])
+    np.testing.assert_array_equal(oks, g["oks"])
+    np.testing.assert_allclose(err, g["err"], rtol=1e-15, atol=0)
+    # stronger than the contract: expected to be identical
+    assert np.abs(kpts - g["kpts"]).max() == 0.0
+
+
+def test_single_crop_shapes_match_reference(pp):
+    """B == 1 is the only case the reference supports: (1,K,2)/(1,K)/(1,1,K)."""
+    g, hm, aux = load_decode_fixture("decode_k17_peaked.npz")
+    codec = pp.Codec(pp.ProbMap((192, 256), (48, 64), g["sigmas"]))
+    out = codec.decode(_dev([a[:1] for a in (hm, *aux)]))
+    assert out[0][0].shape == (1, 17, 2) and out[0][1].shape == (1, 17)
+    assert all(o.shape == (1, 1, 17) for o in out[1:])
+    k2, s2 = codec.decode_heatmap(hm[0])                       # numpy (K,H,W) like loss.py:531
+    np.testing.assert_array_equal(k2, out[0][0])
+    np.testing.assert_array_equal(s2, out[0][1])
+    k3, _ = codec.decode_heatmap(torch.from_numpy(hm[0]).cuda())
+    np.testing.assert_array_equal(k3, out[0][0])
+
+
+def test_convolved_maps_bit_exact(pp):
+    g = np.load(os.path.join(GOLDEN, "convmaps_k17.npz"))
+    hm = orc.synthetic_heatmaps(1, 17, 64, 48, 4321, "peaked")[0]
+    before = hm.copy()
+    locs, vals, conv = pp.get_heatmap_expected_value(hm, orc.COCO17_SIGMAS, return_heatmap=True)
+    np.testing.assert_array_equal(hm, before)                  # input never mutated
+    assert locs.shape == (17, 2) and vals.shape == (17,) and conv.shape == (17, 64, 48)
+    np.testing.assert_array_equal(conv, g["conv_scipy"])
+    np.testing.assert_array_equal(locs, g["locs"])
+    np.testing.assert_array_equal(vals, g["vals"])
+
+
+def test_large_map_fallback_reference_test_shape(pp):
+    """256x256 does not fit in LDS -> three-pass global path (reference tests/test_heatmap.py:6)."""
+    g = np.load(os.path.join(GOLDEN, "bigmap_256.npz"))
+    rng = np.random.default_rng(2024)
+    big = rng.random((20, 256, 256), dtype=np.float32)
+    sig = rng.random(20, dtype=np.float32)
+    locs, vals, conv = pp.get_heatmap_expected_value(big, sig, return_heatmap=True)
+    np.testing.assert_array_equal(conv[:, ::16, ::16], g["conv_sample"])
+    np.testing.assert_array_equal(locs, g["locs"])
+    np.testing.assert_array_equal(vals, g["vals"])
+    # the reference's own assertion: the two back-ends agree to rtol 1e-5
+    _, _, ref_conv = orc.heatmap_expected_value(big[:2], sig[:2], "torch", return_heatmap=True)
+    np.testing.assert_allclose(conv[:2], ref_conv, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (1, 4, 4, 3), (2, 3, 33, 31), (1, 2, 128, 96),
+                                   (1, 1, 1, 1), (2, 17, 64, 48)])
+@pytest.mark.parametrize("kind", ["uniform", "peaked"])
+def test_ragged_shapes_against_oracle(pp, shape, kind):
+    """Odd sizes (no float4 path), maps smaller than the kernel radius (multiple
+    reflections), the largest map that still fits LDS (128x96)."""
+    B, K, H, W = shape
+    hm = orc.synthetic_heatmaps(B, K, H, W, seed=H * 1000 + W, kind=kind)
+    sig = np.random.default_rng(K).uniform(0.02, 0.2, K)
+    got_l, got_v = pp.get_heatmap_expected_value(hm, sig)
+    for b in range(B):
+        if min(H, W) > 9:
+            want_l, want_v = orc.heatmap_expected_value(hm[b], sig, "scipy")
+        else:   # the torch back-end cannot pad by more than the size; scipy can
+            want_l, want_v = orc.heatmap_expected_value(hm[b], sig, "scipy")
+        gl = got_l[b] if B > 1 else got_l
+        gv = got_v[b] if B > 1 else got_v
+        np.testing.assert_array_equal(gl, want_l)
+        np.testing.assert_array_equal(gv, want_v)
+
+
+def test_edge_maps_zero_flat_ties_negative_nan(pp):
+    K, H, W = 8, 64, 48
+    hm = np.zeros((K, H, W), np.float32)
+    hm[1] = 1.0                                   # saturated: every pixel ties -> index 0
+    hm[2, 10, 20] = hm[2, 40, 5] = 0.7            # two equal peaks -> first in row-major order
+    hm[3, H - 1, W - 1] = 1.0                     # corner
+    hm[4] = -np.random.default_rng(0).random((H, W), dtype=np.float32)   # negative raw input
+    hm[5, 30, 0] = 0.9                            # border column
+    hm[6, 20:23, 20:23] = 1.0                     # plateau: dxx == 0 -> 1e-6 branch
+    hm[7] = np.random.default_rng(1).random((H, W), dtype=np.float32)
+    hm[7, 13, 17] = np.nan                        # np.argmax returns the first NaN
+    sig = orc.COCO17_SIGMAS[:K]
+    with np.errstate(all="ignore"):
+        want_l, want_v, want_c = orc.heatmap_expected_value(hm, sig, "scipy", return_heatmap=True)
+    got_l, got_v, got_c = pp.get_heatmap_expected_value(hm, sig, return_heatmap=True)
+    np.testing.assert_array_equal(got_c[:7], want_c[:7])
+    np.testing.assert_array_equal(got_l[:7], want_l[:7])
+    np.testing.assert_array_equal(got_v[:7], want_v[:7])
+    assert np.array_equal(got_l[0], [0, 0]) and got_v[0] == 0
+    # NaN map: same (NaN-poisoned) peak location as numpy's argmax on the reference map
+    assert np.isnan(got_c[7]).any()
+    np.testing.assert_array_equal(np.isnan(got_c[7]), np.isnan(want_c[7]))
+    np.testing.assert_array_equal(got_l[7], want_l[7])
+
+
+def test_empty_batch(pp):
+    codec = pp.Codec(pp.ProbMap((192, 256), (48, 64), orc.COCO17_SIGMAS))
+    z = torch.zeros((0, 17, 64, 48), device="cuda")
+    a = torch.zeros((0, 17, 1, 1), device="cuda")
+    (kpts, scores), prob, *_ = codec.decode((z, a, a, a, a))
+    assert kpts.shape == (0, 17, 2) and scores.shape == (0, 17) and prob.shape == (0, 1, 17)
+
+
+def test_full_size_batch_properties(pp):
+    """BASELINE sizes (B=64 K=17 64x48 and 128 crops K=133 96x72): too slow for the
+    scipy oracle as a whole, so check size-independent properties + a sampled
+    subset against the oracle."""
+    for (B, K, H, W, insz) in ((64, 17, 64, 48, (192, 256)), (128, 133, 96, 72, (288, 384))):
+        sig = orc.COCO17_SIGMAS if K == 17 else np.random.default_rng(133).uniform(0.02, 0.11, K)
+        rng = np.random.default_rng(B)
+        base = orc.synthetic_heatmaps(2, K, H, W, seed=B, kind="peaked")
+        hm = np.tile(base, (B // 2, 1, 1, 1))                 # crops repeat with period 2
+        t = torch.from_numpy(hm).cuda()
+        probmap = pp.ProbMap(insz, (W, H), sig)
+        out = probmap.decode_device(t)
+        kpts, scores = out["kpts"].cpu().numpy(), out["scores"].cpu().numpy()
+        # batch independence: identical crops decode identically wherever they sit in the batch
+        np.testing.assert_array_equal(kpts[0::2], np.broadcast_to(kpts[0], kpts[0::2].shape))
+        np.testing.assert_array_equal(kpts[1::2], np.broadcast_to(kpts[1], kpts[1::2].shape))
+        # permutation equivariance over keypoint channels with equal sigma is covered by the
+        # oracle comparison on the two distinct crops:
+        want_k, want_s = zip(*(orc.probmap_decode(base[b], insz, (W, H), sig) for b in range(2)))
+        np.testing.assert_allclose(kpts[:2], np.concatenate(want_k), rtol=0, atol=ATOL_KPTS)
+        np.testing.assert_array_equal(scores[:2], np.concatenate(want_s))
+        # bounds: sub-pixel shift of an interior strict maximum is within half a pixel ... the
+        # decoded point stays inside the rescaled map
+        assert np.all(kpts[..., 0] > -0.5 * insz[0] / (W - 1)) and np.all(kpts[..., 0] < insz[0] * (1 + 0.5 / (W - 1)))
+        # idempotence of the launch (no hidden state): second run is bit-identical
+        again = probmap.decode_device(t)["kpts"].cpu().numpy()
+        np.testing.assert_array_equal(again, kpts)
