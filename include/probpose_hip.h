@@ -42,6 +42,8 @@ extern "C" {
 #define PP_EPI_RESIDUAL 8               /* out_f32 = residual_f32 + (acc + bias)      */
 #define PP_EPI_OUT_F32 16               /* store fp32 regardless of the storage dtype */
 #define PP_EPI_ROWBIAS 32               /* + rowbias[(m % rowbias_period) * ldc + n]  (pos_embed) */
+#define PP_EPI_HEATMAP 64               /* head.py:526-532: f32 NCHW store of clamp(v / temperature, 0, 1):
+                                           C[((r / hm_HW) * hm_K + n) * hm_HW + r % hm_HW], r = output row */
 
 int pp_version(void);
 const char *pp_last_error(void);
@@ -96,14 +98,18 @@ typedef struct pp_gemm_args {
   const float *residual;        /* [M,ldc] f32 (PP_EPI_RESIDUAL)        */
   const float *rowbias;         /* [rowbias_period, ldc] f32            */
   const int32_t *rowoff;        /* [segs*M] element offsets or NULL     */
+  const int32_t *out_rowmap;    /* [M] output row of GEMM row m, or NULL (identity);
+                                   the stride-2 deconvolution parities scatter through it */
   int M, N, Kd;
   int lda, ldw, ldc;
   int seg_len;                  /* K-segment length for the gather      */
   int rowbias_period;
   int batch;
-  long long strideA, strideW, strideC, strideBias;
+  long long strideA, strideW, strideC, strideBias, strideRowoff, strideRowmap;
   int dtype;                    /* PP_F32 | PP_BF16                     */
   int epilogue;                 /* PP_EPI_* flags                       */
+  int hm_K, hm_HW;              /* PP_EPI_HEATMAP geometry              */
+  float hm_temperature;         /* head.py:107 (0.5)                    */
 } pp_gemm_args;
 int pp_gemm(const pp_gemm_args *args, void *stream);
 
@@ -127,11 +133,6 @@ int pp_patchify(const float *x, void *out, int B, int H, int W, int patch, int d
  * x [B, h, w, C] -> out [B, h/kh, w/kw, C]. */
 int pp_maxpool_relu(const void *x, void *out, int B, int h, int w, int C, int kh, int kw,
                     int dtype, void *stream);
-
-/* Final 1x1 conv + temperature + clamp, NHWC -> NCHW (head.py:525-532):
- * x [B*HW, Cin] -> heatmaps [B,K,H*W] f32 = clamp((x*W^T + b) / temperature, 0, 1). */
-int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B,
-                     int HW, int Cin, int K, float inv_temperature, int dtype, void *stream);
 
 /* Aux tail: 1x1 conv C->K on pooled 1x1 features + Sigmoid/ReLU (head.py:277-286,:391-400).
  * x [4 branches][B, C] -> out [4][B,K] f32 (branches 0..2 sigmoid, 3 relu). */

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libprobpose_hip.so")
 PP_F32, PP_BF16 = 0, 1
 PP_MAX_RADIUS = 9
 PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
-EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS, EPI_HEATMAP = 1, 2, 4, 8, 16, 32, 64
 
 _lock = threading.Lock()
 _lib = None
@@ -25,13 +25,14 @@ class GemmArgs(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
         ("bias", C.c_void_p), ("residual", C.c_void_p), ("rowbias", C.c_void_p),
-        ("rowoff", C.c_void_p),
+        ("rowoff", C.c_void_p), ("out_rowmap", C.c_void_p),
         ("M", C.c_int), ("N", C.c_int), ("Kd", C.c_int),
         ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int),
         ("seg_len", C.c_int), ("rowbias_period", C.c_int), ("batch", C.c_int),
         ("strideA", C.c_longlong), ("strideW", C.c_longlong), ("strideC", C.c_longlong),
-        ("strideBias", C.c_longlong),
+        ("strideBias", C.c_longlong), ("strideRowoff", C.c_longlong), ("strideRowmap", C.c_longlong),
         ("dtype", C.c_int), ("epilogue", C.c_int),
+        ("hm_K", C.c_int), ("hm_HW", C.c_int), ("hm_temperature", C.c_float),
     ]
 
 
@@ -47,7 +48,6 @@ _SIGNATURES = {
     "pp_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "pp_final_heatmap": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "pp_aux_tail": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_tokens_to_nchw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_nchw_to_tokens": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),

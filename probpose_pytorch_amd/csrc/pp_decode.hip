@@ -284,11 +284,11 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
                              float *out_locs, float *out_aux, double *out_err, float *out_conv,
                              void *workspace, void *stream) {
   using namespace pp;
-  PP_REQUIRE(heatmaps && taps && radius, "pp_decode_f32: null input");
   PP_REQUIRE(B >= 0 && K > 0 && H > 0 && W > 0, "pp_decode_f32: bad shape B=%d K=%d H=%d W=%d", B, K,
              H, W);
+  if (B == 0) return 0;  // empty batch: nothing to launch (buffers may be null)
+  PP_REQUIRE(heatmaps && taps && radius, "pp_decode_f32: null input");
   PP_REQUIRE((long long)H * W < (1ll << 30), "pp_decode_f32: map too large");
-  if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   DecodeOut o{out_kpts, out_scores, out_locs, out_aux, out_err};
   const int maps = B * K;

@@ -1,0 +1,291 @@
+// MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,Kd] * W[N,Kd]^T), fp32 accumulate.
+//
+// One kernel family serves every dense contraction of the path (patch-embed,
+// qkv, proj, fc1, fc2, 3x3 aux convolutions, the four stride-2 deconvolution
+// parities, the final 1x1 heatmap layer): both operands are K-contiguous rows,
+// A rows optionally addressed through a gather table (implicit GEMM, no im2col
+// buffer), C rows optionally scattered through a row map.
+//
+// Structure (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves as
+// 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles), K-tiles of 128 B per row
+// (64 bf16 / 32 fp32) staged HBM->LDS by global_load_lds_dwordx4 (no VGPR
+// round trip) into a double buffer, XOR-swizzled on the SOURCE address so the
+// LDS image stays lane-linear for the DMA while ds_read_b128 fragment reads
+// are bank-conflict free.  bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode):
+// v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain.
+#include "pp_common.h"
+
+namespace pp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROW_BYTES = 128;                 // bytes of K per staged row
+constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per buffer
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_LDS = 4 * TILE_BYTES;       // A0 B0 A1 B1 = 64 KiB
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+struct GemmParams {
+  const char *A;
+  const char *W;
+  char *C;
+  const float *bias;
+  const float *residual;
+  const float *rowbias;
+  const int32_t *rowoff;
+  const int32_t *out_rowmap;
+  int M, N, Kd;
+  int lda, ldw, ldc;
+  int seg_len, rowbias_period;
+  long long strideA, strideW, strideC, strideBias, strideRowoff, strideRowmap;
+  int epilogue;
+  int hm_K, hm_HW;
+  float hm_temperature;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = ROW_BYTES / ES;  // elements of K per tile
+
+  // ---- tile assignment: XCD-aware remap (blocks b, b+8 share an XCD/L2) so
+  // the tiles sharing one A row-panel run on one XCD back to back.
+  const int ntiles = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+  }
+  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const char *Ab = p.A + (size_t)z * p.strideA * ES;
+  const char *Wb = p.W + (size_t)z * p.strideW * ES;
+  const int32_t *rowoff = p.rowoff ? p.rowoff + (size_t)z * p.strideRowoff : nullptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- staging geometry: each wave issues 4 A + 4 B DMA pieces (8 rows x 128 B) per K-tile.
+  // lane -> (row in piece, physical 16-B chunk); logical chunk = physical ^ (row & 7).
+  const int prow = lane >> 3, pchunk = lane & 7;
+  int a_row[4], w_row[4];
+  const char *a_src[4];
+  const char *w_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 8 + prow;  // row inside the 128-row tile
+    const int lchunk = pchunk ^ (r & 7);
+    a_row[j] = min(m0 + r, p.M - 1);          // tail rows re-read the last row (never stored)
+    w_row[j] = n0 + r;
+    a_src[j] = Ab + (size_t)a_row[j] * p.lda * ES + lchunk * 16;
+    w_src[j] = (w_row[j] < p.N) ? Wb + (size_t)w_row[j] * p.ldw * ES + lchunk * 16
+                                : (const char *)g_zero_page + lchunk * 16;
+  }
+  const int lchunk_off = (pchunk ^ prow) * 16;  // (row & 7) == prow for every piece
+  const int nkt = p.Kd / BK;
+
+  auto stage = [&](int kt, int buf) {
+    char *ldsA = smem + buf * 2 * TILE_BYTES + wave * 4 * 1024;
+    char *ldsB = ldsA + TILE_BYTES;
+    const size_t koff = (size_t)kt * ROW_BYTES;
+    if (rowoff) {
+      const int k0 = kt * BK;
+      const int seg = k0 / p.seg_len;
+      const int kin = k0 - seg * p.seg_len;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = rowoff[(size_t)seg * p.M + a_row[j]];
+        const char *src = off >= 0 ? Ab + ((size_t)off + kin) * ES + lchunk_off
+                                   : (const char *)g_zero_page + lchunk_off;
+        glds16(src, ldsA + j * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) glds16(a_src[j] + koff, ldsA + j * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      glds16(w_row[j] < p.N ? w_src[j] + koff : w_src[j], ldsB + j * 1024);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses: row = tile row (lane & 15), logical chunk = 4*s + (lane >> 4)
+  const int frow = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const char *ldsA = smem + buf * 2 * TILE_BYTES;
+    const char *ldsB = ldsA + TILE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + frow;
+        af[i] = *reinterpret_cast<const uint4 *>(ldsA + ra * ROW_BYTES + (((4 * s + fq) ^ (ra & 7)) << 4));
+        const int rb = wn * 64 + i * 16 + frow;
+        bf[i] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * s + fq) ^ (rb & 7)) << 4));
+      }
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                *reinterpret_cast<bf16x8 *>(&af[i]), *reinterpret_cast<bf16x8 *>(&bf[j]), acc[i][j], 0, 0, 0);
+      } else {
+        // fp32: the chunk holds 4 consecutive k; MFMA step e takes element e of every lane's
+        // chunk (k slots 16s + 4*fq + e, the same permutation on both operands).
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  __uint_as_float(reinterpret_cast<const unsigned *>(&af[i])[e]),
+                  __uint_as_float(reinterpret_cast<const unsigned *>(&bf[j])[e]), acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: DMA of tile t+1 in flight while tile t feeds the MFMAs
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt - 1; ++kt) {
+    stage(kt + 1, cur ^ 1);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  compute(cur);
+
+  // ---- epilogue.  16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  const int epi = p.epilogue;
+  const float *bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const int32_t *rowmap = p.out_rowmap ? p.out_rowmap + (size_t)z * p.strideRowmap : nullptr;
+  char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
+  const float *Rb = p.residual ? p.residual + (size_t)z * p.strideC : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mbase = m0 + wm * 64 + i * 16 + fq * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + frow;
+      if (n >= p.N) continue;
+      const float bn = (epi & PP_EPI_BIAS) ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = mbase + e;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e] + bn;
+        if (epi & PP_EPI_ROWBIAS) v += p.rowbias[(size_t)(m % p.rowbias_period) * p.ldc + n];
+        if (epi & PP_EPI_GELU) v = gelu_erf(v);
+        if (epi & PP_EPI_RELU) v = fmaxf(v, 0.f);
+        const int r = rowmap ? rowmap[m] : m;
+        if (epi & PP_EPI_HEATMAP) {
+          v = fminf(fmaxf(v / p.hm_temperature, 0.f), 1.f);
+          const int b = r / p.hm_HW, hw = r - b * p.hm_HW;
+          reinterpret_cast<float *>(Cb)[((size_t)b * p.hm_K + n) * p.hm_HW + hw] = v;
+          continue;
+        }
+        const size_t idx = (size_t)r * p.ldc + n;
+        if (epi & PP_EPI_RESIDUAL) v += Rb[idx];
+        if (epi & PP_EPI_OUT_F32)
+          reinterpret_cast<float *>(Cb)[idx] = v;
+        else
+          Store<T>::st(reinterpret_cast<T *>(Cb) + idx, v);
+      }
+    }
+  }
+}
+
+}  // namespace pp
+
+extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
+  using namespace pp;
+  PP_REQUIRE(a, "pp_gemm: null args");
+  PP_REQUIRE(a->dtype == PP_F32 || a->dtype == PP_BF16, "pp_gemm: bad dtype %d", a->dtype);
+  const int es = a->dtype == PP_BF16 ? 2 : 4;
+  const int bk = ROW_BYTES / es;
+  PP_REQUIRE(a->M >= 0 && a->N > 0 && a->Kd > 0, "pp_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->Kd);
+  if (a->M == 0 || a->batch == 0) return 0;
+  PP_REQUIRE(a->A && a->W && a->C, "pp_gemm: null operand");
+  PP_REQUIRE(a->Kd % bk == 0, "pp_gemm: K=%d must be a multiple of %d for this dtype", a->Kd, bk);
+  PP_REQUIRE(a->lda % (16 / es) == 0 && a->ldw % (16 / es) == 0,
+             "pp_gemm: lda/ldw must keep rows 16-byte aligned");
+  PP_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->W & 15) == 0, "pp_gemm: operands must be 16-byte aligned");
+  if (a->rowoff)
+    PP_REQUIRE(a->seg_len > 0 && a->seg_len % bk == 0 && a->Kd % a->seg_len == 0,
+               "pp_gemm: gather segment length %d must divide K=%d and be a multiple of %d", a->seg_len,
+               a->Kd, bk);
+  if (a->epilogue & PP_EPI_BIAS) PP_REQUIRE(a->bias, "pp_gemm: PP_EPI_BIAS without bias");
+  if (a->epilogue & PP_EPI_RESIDUAL) PP_REQUIRE(a->residual, "pp_gemm: PP_EPI_RESIDUAL without residual");
+  if (a->epilogue & PP_EPI_ROWBIAS)
+    PP_REQUIRE(a->rowbias && a->rowbias_period > 0, "pp_gemm: PP_EPI_ROWBIAS without rowbias/period");
+  if (a->epilogue & PP_EPI_HEATMAP)
+    PP_REQUIRE(a->hm_K >= a->N && a->hm_HW > 0 && a->hm_temperature != 0.f, "pp_gemm: bad heatmap epilogue");
+  GemmParams p;
+  p.A = (const char *)a->A;
+  p.W = (const char *)a->W;
+  p.C = (char *)a->C;
+  p.bias = a->bias;
+  p.residual = a->residual;
+  p.rowbias = a->rowbias;
+  p.rowoff = a->rowoff;
+  p.out_rowmap = a->out_rowmap;
+  p.M = a->M; p.N = a->N; p.Kd = a->Kd;
+  p.lda = a->lda; p.ldw = a->ldw; p.ldc = a->ldc;
+  p.seg_len = a->seg_len > 0 ? a->seg_len : a->Kd;
+  p.rowbias_period = a->rowbias_period;
+  p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
+  p.strideBias = a->strideBias; p.strideRowoff = a->strideRowoff; p.strideRowmap = a->strideRowmap;
+  p.epilogue = a->epilogue;
+  p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
+  p.tiles_m = cdiv(a->M, BM);
+  p.tiles_n = cdiv(a->N, BN);
+  const int batch = a->batch > 0 ? a->batch : 1;
+  PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
+  dim3 grid(p.tiles_m * p.tiles_n, batch);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->dtype == PP_BF16) {
+    static thread_local bool attr = false;
+    if (!attr) {
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<bf16_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel<bf16_t>, grid, dim3(GEMM_THREADS), GEMM_LDS, s, p);
+  } else {
+    static thread_local bool attr = false;
+    if (!attr) {
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<float>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel<float>, grid, dim3(GEMM_THREADS), GEMM_LDS, s, p);
+  }
+  PP_CHECK_LAUNCH("gemm_kernel");
+  return 0;
+}

@@ -1,0 +1,422 @@
+// Memory-bound companions of the MFMA GEMM on the ProbPose forward path:
+// LayerNorm, patch im2col, max-pool+ReLU, the aux-branch 1x1 tail, layout
+// transposes, and the exact-fp32 VALU attention used in parity mode (the bf16
+// MFMA attention lives in pp_attention.hip).
+#include "pp_common.h"
+
+namespace pp {
+
+// ---------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row held in registers (C <= 2048) so HBM/L2
+// is read once; fp32 statistics (two-pass, like torch's RowwiseMoments result).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float eps,
+                                                        int rows, int C, T *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float *xr = x + (size_t)row * C;
+  T *orow = out + (size_t)row * C;
+  constexpr int MAXV = 8;
+  if ((C & 3) == 0 && C <= MAXV * 256) {
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        v[i] = *reinterpret_cast<const float4 *>(xr + c);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+        const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y,
+                    o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<float4 *>(orow + c) = make_float4(o0, o1, o2, o3);
+        } else {
+          ushort4 pk;
+          pk.x = f32_to_bf16(o0); pk.y = f32_to_bf16(o1); pk.z = f32_to_bf16(o2); pk.w = f32_to_bf16(o3);
+          *reinterpret_cast<ushort4 *>(orow + c) = pk;
+        }
+      }
+    }
+    return;
+  }
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] - mean;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  for (int c = lane; c < C; c += 64) Store<T>::st(orow + c, (xr[c] - mean) * rstd * gamma[c] + beta[c]);
+}
+
+// ---------------------------------------------------------------------------
+// Patch im2col (+cast): NCHW fp32 image -> rows of 3*p*p, k = c*p*p + py*p + px.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ x, T *__restrict__ out,
+                                                       int B, int H, int W, int p) {
+  const int W4 = W >> 2;
+  const long long total = (long long)B * 3 * H * W4;
+  const int gw = W / p, gh = H / p;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xq = (int)(i % W4);
+    long long t = i / W4;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % 3);
+    const int b = (int)(t / 3);
+    const int x0 = xq * 4;
+    const int gy = y / p, py = y - gy * p, gx = x0 / p, px = x0 - gx * p;
+    if (gy >= gh || gx >= gw) continue;  // pixels beyond the last full patch are dropped (conv stride p)
+    const float4 v = *reinterpret_cast<const float4 *>(x + (((size_t)b * 3 + c) * H + y) * W + x0);
+    T *o = out + ((size_t)(b * gh + gy) * gw + gx) * (3 * p * p) + (c * p + py) * p + px;
+    Store<T>::st(o + 0, v.x); Store<T>::st(o + 1, v.y); Store<T>::st(o + 2, v.z); Store<T>::st(o + 3, v.w);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// MaxPool(kh,kw) stride (kh,kw) + ReLU, channels-last rows, 16 B per lane.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_relu_kernel(const T *__restrict__ x, T *__restrict__ out,
+                                                           int B, int h, int w, int C, int kh, int kw) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int oh = h / kh, ow = w / kw, CV = C / VEC;
+  const long long total = (long long)B * oh * ow * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long long t = i / CV;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int b = (int)(t / oh);
+    float m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = 0.f;  // ReLU folded in: max(0, max(window))
+    for (int dy = 0; dy < kh; ++dy)
+      for (int dx = 0; dx < kw; ++dx) {
+        const T *src = x + (((size_t)b * h + oy * kh + dy) * w + ox * kw + dx) * C + cv * VEC;
+        const uint4 raw = *reinterpret_cast<const uint4 *>(src);
+        const T *e8 = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float f = Store<T>::ld(e8 + e);
+          m[e] = (f > m[e] || f != f) ? f : m[e];  // NaN propagates like torch's max_pool2d
+        }
+      }
+    uint4 pk;
+    T *o8 = reinterpret_cast<T *>(&pk);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) Store<T>::st(o8 + e, m[e]);
+    *reinterpret_cast<uint4 *>(out + (((size_t)b * oh + oy) * ow + ox) * C + cv * VEC) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Aux tail: per branch 1x1 conv C->K on the pooled 1x1 feature + Sigmoid/ReLU.
+// x [B, nbr*C] (branch-major columns), w [nbr][K][C], bias [nbr][K], out [nbr][B][K].
+// One wave per output value.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void aux_tail_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                       const float *__restrict__ bias,
+                                                       float *__restrict__ out, int B, int C, int K,
+                                                       int nbr, unsigned relu_mask) {
+  const int lane = threadIdx.x & 63;
+  const long long o = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= (long long)nbr * B * K) return;
+  const int k = (int)(o % K);
+  const int b = (int)((o / K) % B);
+  const int br = (int)(o / ((long long)K * B));
+  const T *xr = x + ((size_t)b * nbr + br) * C;
+  const T *wr = w + ((size_t)br * K + k) * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += Store<T>::ld(xr + c) * Store<T>::ld(wr + c);
+  s = wave_sum(s) + bias[br * K + k];
+  if (lane == 0) out[o] = ((relu_mask >> br) & 1) ? fmaxf(s, 0.f) : 1.0f / (1.0f + expf(-s));
+}
+
+// ---------------------------------------------------------------------------
+// Batched transpose with dtype change: in [B, R, S] -> out [B, S, R].
+// ---------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI *__restrict__ in, TO *__restrict__ out,
+                                                        int R, int S) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const TI *ib = in + (size_t)b * R * S;
+  TO *ob = out + (size_t)b * R * S;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && s0 + tx < S) tile[i][tx] = Store<TI>::ld(ib + (size_t)(r0 + i) * S + s0 + tx);
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (s0 + i < S && r0 + tx < R) Store<TO>::st(ob + (size_t)(s0 + i) * R + r0 + tx, tile[tx][i]);
+}
+
+// ---------------------------------------------------------------------------
+// Exact-fp32 attention on the VALU (parity mode and head dims the MFMA kernel
+// does not cover).  One workgroup per (crop, head); one query row per thread;
+// K/V staged through LDS as fp32 in chunks; online softmax in groups of 8 keys.
+// ---------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attention_valu_kernel(const T *__restrict__ qkv,
+                                                             T *__restrict__ out, int N, int heads,
+                                                             float scale, int KC) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *Ks = reinterpret_cast<float *>(smem);  // [KC][HD]
+  float *Vs = Ks + (size_t)KC * HD;             // [KC][HD]
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int C = heads * HD, ld = 3 * C;
+  const T *base = qkv + (size_t)b * N * ld;
+  for (int q0 = 0; q0 < N; q0 += blockDim.x) {
+    const int qi = q0 + threadIdx.x;
+    const bool active = qi < N;
+    float q[HD], o[HD];
+    float m = -__builtin_inff(), l = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      q[d] = active ? Store<T>::ld(base + (size_t)qi * ld + h * HD + d) * scale : 0.f;
+      o[d] = 0.f;
+    }
+    for (int k0 = 0; k0 < N; k0 += KC) {
+      const int kc = min(KC, N - k0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < kc * HD; i += blockDim.x) {
+        const int kk = i / HD, d = i - kk * HD;
+        const T *row = base + (size_t)(k0 + kk) * ld + h * HD + d;
+        Ks[i] = Store<T>::ld(row + C);
+        Vs[i] = Store<T>::ld(row + 2 * C);
+      }
+      __syncthreads();
+      for (int g = 0; g < kc; g += 8) {
+        float s[8];
+        float gm = -__builtin_inff();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float a = 0.f;
+          if (g + u < kc) {
+            const float4 *kr = reinterpret_cast<const float4 *>(Ks + (size_t)(g + u) * HD);
+#pragma unroll
+            for (int d4 = 0; d4 < HD / 4; ++d4) {
+              const float4 kv = kr[d4];
+              a = fmaf(q[4 * d4 + 0], kv.x, a);
+              a = fmaf(q[4 * d4 + 1], kv.y, a);
+              a = fmaf(q[4 * d4 + 2], kv.z, a);
+              a = fmaf(q[4 * d4 + 3], kv.w, a);
+            }
+          } else {
+            a = -__builtin_inff();
+          }
+          s[u] = a;
+          gm = fmaxf(gm, a);
+        }
+        const float mn = fmaxf(m, gm);
+        const float alpha = expf(m - mn);  // first group: exp(-inf) = 0
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (g + u < kc) {
+            const float pu = expf(s[u] - mn);
+            l += pu;
+            const float4 *vr = reinterpret_cast<const float4 *>(Vs + (size_t)(g + u) * HD);
+#pragma unroll
+            for (int d4 = 0; d4 < HD / 4; ++d4) {
+              const float4 vv = vr[d4];
+              o[4 * d4 + 0] = fmaf(pu, vv.x, o[4 * d4 + 0]);
+              o[4 * d4 + 1] = fmaf(pu, vv.y, o[4 * d4 + 1]);
+              o[4 * d4 + 2] = fmaf(pu, vv.z, o[4 * d4 + 2]);
+              o[4 * d4 + 3] = fmaf(pu, vv.w, o[4 * d4 + 3]);
+            }
+          }
+        }
+        m = mn;
+      }
+    }
+    if (active) {
+      const float inv = 1.0f / l;
+      T *orow = out + ((size_t)b * N + qi) * C + h * HD;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) Store<T>::st(orow + d, o[d] * inv);
+    }
+  }
+}
+
+template <typename T, int HD>
+static int launch_attention_valu(const void *qkv, void *out, int B, int N, int heads, hipStream_t s) {
+  int KC = (64 * 1024) / (2 * HD * 4);
+  KC = (KC / 8) * 8;
+  if (KC > N) KC = ((N + 7) / 8) * 8;
+  const size_t lds = (size_t)2 * KC * HD * 4;
+  int threads = ((N + 63) / 64) * 64;
+  if (threads > 256) threads = 256;
+  const float scale = 1.0f / sqrtf((float)HD);
+  hipLaunchKernelGGL((attention_valu_kernel<T, HD>), dim3(B * heads), dim3(threads), lds, s,
+                     (const T *)qkv, (T *)out, N, heads, scale, KC);
+  PP_CHECK_LAUNCH("attention_valu_kernel");
+  return 0;
+}
+
+template <typename T>
+int attention_valu(const void *qkv, void *out, int B, int N, int heads, int hd, hipStream_t s) {
+  switch (hd) {
+    case 32: return launch_attention_valu<T, 32>(qkv, out, B, N, heads, s);
+    case 64: return launch_attention_valu<T, 64>(qkv, out, B, N, heads, s);
+    case 80: return launch_attention_valu<T, 80>(qkv, out, B, N, heads, s);
+    default: return fail("pp_attention: head_dim %d not supported (32, 64, 80)", hd);
+  }
+}
+template int attention_valu<float>(const void *, void *, int, int, int, int, hipStream_t);
+template int attention_valu<bf16_t>(const void *, void *, int, int, int, int, hipStream_t);
+
+static int grid_for(long long work_items) {
+  long long g = (work_items + 255) / 256;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace pp
+
+using namespace pp;
+
+extern "C" int pp_layernorm(const float *x, const float *gamma, const float *beta, float eps, int rows,
+                            int C, void *out, int dtype, void *stream) {
+  PP_REQUIRE(rows >= 0 && C > 0, "pp_layernorm: bad shape");
+  if (rows == 0) return 0;
+  PP_REQUIRE(x && gamma && beta && out, "pp_layernorm: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = cdiv(rows, 4);
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C,
+                       (bf16_t *)out);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C,
+                       (float *)out);
+  else
+    return fail("pp_layernorm: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("layernorm_kernel");
+  return 0;
+}
+
+extern "C" int pp_patchify(const float *x, void *out, int B, int H, int W, int patch, int dtype,
+                           void *stream) {
+  PP_REQUIRE(B >= 0 && H > 0 && W > 0 && patch > 0, "pp_patchify: bad shape");
+  if (B == 0) return 0;
+  PP_REQUIRE(x && out, "pp_patchify: null pointer");
+  PP_REQUIRE(W % 4 == 0 && patch % 4 == 0, "pp_patchify: W and patch must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for((long long)B * 3 * H * (W / 4));
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t *)out, B, H, W, patch);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float *)out, B, H, W, patch);
+  else
+    return fail("pp_patchify: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("patchify_kernel");
+  return 0;
+}
+
+extern "C" int pp_maxpool_relu(const void *x, void *out, int B, int h, int w, int C, int kh, int kw,
+                               int dtype, void *stream) {
+  PP_REQUIRE(B >= 0 && h > 0 && w > 0 && C > 0 && kh > 0 && kw > 0, "pp_maxpool_relu: bad shape");
+  PP_REQUIRE(h / kh > 0 && w / kw > 0, "pp_maxpool_relu: window %dx%d larger than input %dx%d", kh, kw, h, w);
+  if (B == 0) return 0;
+  PP_REQUIRE(x && out, "pp_maxpool_relu: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int vec = dtype == PP_BF16 ? 8 : 4;
+  PP_REQUIRE(C % vec == 0, "pp_maxpool_relu: C=%d must be a multiple of %d", C, vec);
+  const int grid = grid_for((long long)B * (h / kh) * (w / kw) * (C / vec));
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL(maxpool_relu_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)x,
+                       (bf16_t *)out, B, h, w, C, kh, kw);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL(maxpool_relu_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)x,
+                       (float *)out, B, h, w, C, kh, kw);
+  else
+    return fail("pp_maxpool_relu: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("maxpool_relu_kernel");
+  return 0;
+}
+
+extern "C" int pp_aux_tail(const void *x, const void *w, const float *bias, float *out, int B, int C,
+                           int K, int dtype, void *stream) {
+  PP_REQUIRE(B >= 0 && C > 0 && K > 0, "pp_aux_tail: bad shape");
+  if (B == 0) return 0;
+  PP_REQUIRE(x && w && bias && out, "pp_aux_tail: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int nbr = 4;
+  const unsigned relu_mask = 1u << 3;  // probability, visibility, oks: sigmoid; error: ReLU
+  const int grid = cdiv((long long)nbr * B * K, 4);
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL(aux_tail_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t *)x,
+                       (const bf16_t *)w, bias, out, B, C, K, nbr, relu_mask);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL(aux_tail_kernel<float>, dim3(grid), dim3(256), 0, s, (const float *)x,
+                       (const float *)w, bias, out, B, C, K, nbr, relu_mask);
+  else
+    return fail("pp_aux_tail: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("aux_tail_kernel");
+  return 0;
+}
+
+extern "C" int pp_tokens_to_nchw(const void *x, float *out, int B, int N, int C, int dtype, void *stream) {
+  PP_REQUIRE(B >= 0 && N > 0 && C > 0, "pp_tokens_to_nchw: bad shape");
+  if (B == 0) return 0;
+  PP_REQUIRE(x && out, "pp_tokens_to_nchw: null pointer");
+  PP_REQUIRE(B <= 65535, "pp_tokens_to_nchw: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(C, 32), cdiv(N, 32), B);
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t *)x, out, N, C);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float *)x, out, N, C);
+  else
+    return fail("pp_tokens_to_nchw: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("transpose_kernel");
+  return 0;
+}
+
+extern "C" int pp_nchw_to_tokens(const float *x, void *out, int B, int C, int HW, int dtype, void *stream) {
+  PP_REQUIRE(B >= 0 && HW > 0 && C > 0, "pp_nchw_to_tokens: bad shape");
+  if (B == 0) return 0;
+  PP_REQUIRE(x && out, "pp_nchw_to_tokens: null pointer");
+  PP_REQUIRE(B <= 65535, "pp_nchw_to_tokens: batch too large");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(HW, 32), cdiv(C, 32), B);
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, s, x, (bf16_t *)out, C, HW);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, x, (float *)out, C, HW);
+  else
+    return fail("pp_nchw_to_tokens: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("transpose_kernel");
+  return 0;
+}

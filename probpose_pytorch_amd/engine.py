@@ -1,0 +1,301 @@
+"""Execution plans: packed weights + cached workspaces + the launch sequence of
+the HIP kernels for the ViT backbone and the ProbMapHead.
+
+A plan is built from an ``nn.Module``'s parameters (the modules in
+backbone.py / head.py only hold parameters and structure, mirroring the
+reference's attribute names) and re-built when the parameters change.  All
+activations stay on the device as channels-last rows; the residual stream is
+fp32, GEMM operands are ``dtype`` (bf16: ``v_mfma_f32_16x16x32_bf16``; fp32:
+exact ``v_mfma_f32_16x16x4_f32``).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops, pack
+from .ops import EPI_GELU, EPI_OUT_F32, EPI_RELU
+
+_PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _signature(module: torch.nn.Module):
+    sig = []
+    for t in list(module.parameters()) + list(module.buffers()):
+        sig.append((t.data_ptr(), t._version, t.dtype, t.device))
+    return tuple(sig)
+
+
+def plan_for(module, builder, dtype: torch.dtype, device):
+    """Cached plan of ``module`` for (dtype, device); rebuilt when any parameter changed."""
+    entry = _PLANS.get(module)
+    key = (dtype, str(device))
+    sig = _signature(module)
+    if entry is None or entry[0] != key or entry[1] != sig:
+        entry = (key, sig, builder(module, dtype, device))
+        _PLANS[module] = entry
+    return entry[2]
+
+
+def _dev(t: torch.Tensor, device, dtype=None):
+    t = t.detach()
+    return t.to(device=device, dtype=dtype if dtype is not None else t.dtype).contiguous()
+
+
+class _Workspace:
+    """Named scratch tensors, allocated once per batch size (stable addresses for graph capture)."""
+
+    def __init__(self):
+        self._bufs: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[key] = t
+        return t
+
+
+# ---------------------------------------------------------------------------
+# ViT backbone
+# ---------------------------------------------------------------------------
+class VitPlan:
+    def __init__(self, vit, dtype: torch.dtype, device):
+        self.dtype, self.device = dtype, device
+        pe = vit.patch_embed
+        self.patch = int(pe.patch_size[0])
+        self.img_size = tuple(pe.img_size)
+        self.C = C = vit.embed_dim
+        self.heads = vit.num_heads
+        self.hd = C // self.heads
+        self.N = pe.num_patches
+        self.pe_w = _dev(pe.proj.weight.reshape(C, -1), device, dtype)
+        self.pe_b = _dev(pe.proj.bias, device, torch.float32)
+        self.pos = _dev(vit.pos_embed.reshape(self.N, C), device, torch.float32)
+        self.blocks = []
+        for blk in vit.blocks:
+            self.blocks.append(dict(
+                n1w=_dev(blk.norm1.weight, device, torch.float32), n1b=_dev(blk.norm1.bias, device, torch.float32),
+                eps1=blk.norm1.eps,
+                qkv_w=_dev(blk.attn.qkv.weight, device, dtype), qkv_b=_dev(blk.attn.qkv.bias, device, torch.float32),
+                proj_w=_dev(blk.attn.proj.weight, device, dtype), proj_b=_dev(blk.attn.proj.bias, device, torch.float32),
+                n2w=_dev(blk.norm2.weight, device, torch.float32), n2b=_dev(blk.norm2.bias, device, torch.float32),
+                eps2=blk.norm2.eps,
+                fc1_w=_dev(blk.mlp.fc1.weight, device, dtype), fc1_b=_dev(blk.mlp.fc1.bias, device, torch.float32),
+                fc2_w=_dev(blk.mlp.fc2.weight, device, dtype), fc2_b=_dev(blk.mlp.fc2.bias, device, torch.float32),
+            ))
+        self.nw = _dev(vit.norm.weight, device, torch.float32)
+        self.nb = _dev(vit.norm.bias, device, torch.float32)
+        self.neps = vit.norm.eps
+        self.hidden = self.blocks[0]["fc1_w"].shape[0] if self.blocks else 4 * C
+        self.ws = _Workspace()
+
+    def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B,3,H,W) f32 on the device -> tokens [B*N, C] in the compute dtype
+        (= channels-last (B,gh,gw,C) feature map), final LayerNorm applied."""
+        B, ch, H, W = x.shape
+        if ch != 3 or (H, W) != self.img_size:
+            raise AssertionError(f"Input size ({H}, {W}) doesn't match model {self.img_size}")
+        dev, dt, C, N = self.device, self.dtype, self.C, self.N
+        M = B * N
+        g = self.ws.get
+        a0 = g("a0", (M, 3 * self.patch ** 2), dt, dev)
+        xres = g("xres", (M, C), torch.float32, dev)
+        h = g("h", (M, C), dt, dev)
+        qkv = g("qkv", (M, 3 * C), dt, dev)
+        ao = g("ao", (M, C), dt, dev)
+        hid = g("hid", (M, self.hidden), dt, dev)
+        feats = g("feats", (M, C), dt, dev)
+        ops.patchify(x, a0, self.patch)
+        # patch_embed.proj as a GEMM, + bias, + pos_embed (row m uses pos[m % N]), fp32 residual stream
+        ops.gemm(a0, self.pe_w, xres, M=M, N=C, Kd=a0.shape[1], lda=a0.shape[1], ldw=a0.shape[1], ldc=C,
+                 bias=self.pe_b, rowbias=self.pos, rowbias_period=N, epilogue=EPI_OUT_F32)
+        for b in self.blocks:
+            ops.layernorm(xres, b["n1w"], b["n1b"], b["eps1"], h)
+            ops.linear(h, b["qkv_w"], b["qkv_b"], out=qkv)
+            ops.attention(qkv, ao, B, N, self.heads, self.hd)
+            ops.linear(ao, b["proj_w"], b["proj_b"], out=xres, residual=xres)
+            ops.layernorm(xres, b["n2w"], b["n2b"], b["eps2"], h)
+            ops.linear(h, b["fc1_w"], b["fc1_b"], out=hid, epilogue=EPI_GELU)
+            ops.linear(hid, b["fc2_w"], b["fc2_b"], out=xres, residual=xres)
+        ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
+        return feats
+
+
+def build_vit_plan(vit, dtype, device):
+    return VitPlan(vit, dtype, device)
+
+
+# ---------------------------------------------------------------------------
+# ProbMapHead
+# ---------------------------------------------------------------------------
+AUX_NAMES = ("probability", "visibility", "oks", "error")
+
+
+class HeadPlan:
+    def __init__(self, head, dtype: torch.dtype, device):
+        from torch import nn
+        self.dtype, self.device = dtype, device
+        self.K = head.out_channels
+        self.C = head.in_channels
+        self.temperature = float(head.temperature)
+        if not isinstance(head.normalize_layer, nn.Identity) or head.normalize is not None:
+            raise NotImplementedError(
+                "normalize != None (Sparsemax, sparsemax==0.1.9) has no oracle in the reference "
+                "checkout (parity unpinned) and is not built")
+        # --- heatmap branch: deconvs (+BN+ReLU), optional convs (+BN+ReLU), final conv
+        self.deconvs = []
+        cin = self.C
+        if not isinstance(head.deconv_layers, nn.Identity):
+            layers = list(head.deconv_layers)
+            for i in range(0, len(layers), 3):
+                dc, bn = layers[i], layers[i + 1]
+                k = int(dc.kernel_size[0])
+                wf, bf = pack.fold_bn(dc.weight.detach().float().cpu(), None, bn.weight.detach().cpu(),
+                                      bn.bias.detach().cpu(), bn.running_mean.cpu(), bn.running_var.cpu(),
+                                      bn.eps, out_dim=1)
+                self.deconvs.append(dict(k=k, cin=cin, cout=dc.out_channels,
+                                         w=_dev(pack.pack_deconv_parities(wf, k), device, dtype),
+                                         b=_dev(bf, device, torch.float32)))
+                cin = dc.out_channels
+        self.convs = []
+        if not isinstance(head.conv_layers, nn.Identity):
+            layers = list(head.conv_layers)
+            for i in range(0, len(layers), 3):
+                cv, bn = layers[i], layers[i + 1]
+                wf, bf = pack.fold_bn(cv.weight.detach().float().cpu(),
+                                      None if cv.bias is None else cv.bias.detach().cpu(),
+                                      bn.weight.detach().cpu(), bn.bias.detach().cpu(), bn.running_mean.cpu(),
+                                      bn.running_var.cpu(), bn.eps)
+                self.convs.append(dict(k=int(cv.kernel_size[0]), pad=int(cv.padding[0]), cin=cin,
+                                       cout=cv.out_channels, w=_dev(pack.conv_taps_major(wf), device, dtype),
+                                       b=_dev(bf, device, torch.float32)))
+                cin = cv.out_channels
+        if isinstance(head.final_layer, nn.Identity):
+            raise NotImplementedError("final_layer_kernel_size=None is not built (never used by the reference scripts)")
+        fl = head.final_layer
+        self.final = dict(k=int(fl.kernel_size[0]), pad=int(fl.padding[0]), cin=cin,
+                          w=_dev(pack.conv_taps_major(fl.weight.detach().float().cpu()), device, dtype),
+                          b=_dev(fl.bias.detach().float(), device, torch.float32))
+        # --- four aux branches: [conv3x3+BN, pool, relu] x n -> conv1x1 -> act
+        prob_layers = list(head.probability_layers)
+        n_stage = (len(prob_layers) - 2) // 4
+        self.pools = []
+        for i in range(n_stage):
+            ks = prob_layers[4 * i + 2].kernel_size
+            self.pools.append((int(ks), int(ks)) if isinstance(ks, int) else (int(ks[0]), int(ks[1])))
+        n = len(self.pools)
+        C = self.C
+        stage_w = [[] for _ in range(n)]
+        stage_b = [[] for _ in range(n)]
+        tail_w, tail_b = [], []
+        for name in AUX_NAMES:
+            layers = list(getattr(head, name + "_layers"))
+            assert len(layers) == 4 * n + 2
+            for i in range(n):
+                cv, bn = layers[4 * i], layers[4 * i + 1]
+                wf, bf = pack.fold_bn(cv.weight.detach().float().cpu(), cv.bias.detach().cpu(),
+                                      bn.weight.detach().cpu(), bn.bias.detach().cpu(), bn.running_mean.cpu(),
+                                      bn.running_var.cpu(), bn.eps)
+                stage_w[i].append(pack.conv_taps_major(wf))
+                stage_b[i].append(bf)
+            last = layers[4 * n]
+            tail_w.append(last.weight.detach().float().cpu().reshape(self.K, C))
+            tail_b.append(last.bias.detach().float().cpu())
+        # stage 0 shares its input across branches -> one GEMM with N = 4C; later stages batch = 4
+        self.aux_w = [_dev(torch.cat(stage_w[0], 0), device, dtype)] + \
+                     [_dev(torch.stack(stage_w[i]), device, dtype) for i in range(1, n)]
+        self.aux_b = [_dev(torch.cat(stage_b[0], 0), device, torch.float32)] + \
+                     [_dev(torch.stack(stage_b[i]), device, torch.float32) for i in range(1, n)]
+        self.tail_w = _dev(torch.stack(tail_w), device, dtype)
+        self.tail_b = _dev(torch.stack(tail_b), device, torch.float32)
+        self.ws = _Workspace()
+        self._tables: Dict[tuple, dict] = {}
+
+    # gather/scatter tables depend on (B, h, w) only
+    def _tables_for(self, B: int, h: int, w: int) -> dict:
+        key = (B, h, w)
+        t = self._tables.get(key)
+        if t is not None:
+            return t
+        dev = self.device
+        t = dict(deconv=[], conv=[], aux=[])
+        hh, ww = h, w
+        for d in self.deconvs:
+            ro, rm = pack.deconv_tables(B, hh, ww, d["k"], d["cin"])
+            t["deconv"].append((ro.to(dev), rm.to(dev), hh, ww))
+            hh, ww = 2 * hh, 2 * ww
+        for c in self.convs:
+            t["conv"].append(pack.conv_gather_table(B, hh, ww, c["k"], c["k"], c["pad"], c["pad"], c["cin"]).to(dev)
+                             if c["k"] > 1 else None)
+        f = self.final
+        t["final"] = (pack.conv_gather_table(B, hh, ww, f["k"], f["k"], f["pad"], f["pad"], f["cin"]).to(dev)
+                      if f["k"] > 1 else None)
+        t["hm_hw"] = (hh, ww)
+        ah, aw = h, w
+        for i, p in enumerate(self.pools):
+            stride = self.C if i == 0 else 4 * self.C
+            t["aux"].append((pack.conv_gather_table(B, ah, aw, 3, 3, 1, 1, stride).to(dev), ah, aw))
+            _, _, ah, aw = pack.pool_out(ah, aw, p)
+        if (ah, aw) != (1, 1):
+            raise ValueError(
+                f"alt_head_kernel_sizes {self.pools} reduce a {h}x{w} feature map to {ah}x{aw}; the aux "
+                "branches must end at 1x1 (Codec.decode reshapes them to (B,1,K), reference codec.py:254-257)")
+        self._tables[key] = t
+        return t
+
+    def forward(self, feats: torch.Tensor, B: int, h: int, w: int):
+        """feats: channels-last rows [B*h*w, C] in the compute dtype.
+        Returns (heatmaps (B,K,Hh,Wh) f32, prob, vis, oks, err (B,K,1,1) f32)."""
+        dev, dt, C, K = self.device, self.dtype, self.C, self.K
+        tb = self._tables_for(B, h, w)
+        g = self.ws.get
+        # ---- heatmap branch
+        x, hh, ww, cin = feats, h, w, C
+        for li, (d, (ro, rm, _, _)) in enumerate(zip(self.deconvs, tb["deconv"])):
+            M = B * hh * ww
+            out = g(f"deconv{li}", (4 * M, d["cout"]), dt, dev)
+            ops.gemm(x, d["w"], out, M=M, N=d["cout"], Kd=4 * cin, lda=cin, ldw=4 * cin, ldc=d["cout"],
+                     bias=d["b"], rowoff=ro, seg_len=cin, out_rowmap=rm, batch=4,
+                     strideW=d["cout"] * 4 * cin, strideRowoff=4 * M, strideRowmap=M, epilogue=EPI_RELU)
+            x, hh, ww, cin = out, 2 * hh, 2 * ww, d["cout"]
+        for li, (c, ro) in enumerate(zip(self.convs, tb["conv"])):
+            M = B * hh * ww
+            out = g(f"conv{li}", (M, c["cout"]), dt, dev)
+            kk = c["k"] * c["k"]
+            ops.gemm(x, c["w"], out, M=M, N=c["cout"], Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=c["cout"],
+                     bias=c["b"], rowoff=ro, seg_len=cin, epilogue=EPI_RELU)
+            x, cin = out, c["cout"]
+        M = B * hh * ww
+        heat = torch.empty((B, K, hh, ww), dtype=torch.float32, device=dev)
+        f = self.final
+        kk = f["k"] * f["k"]
+        ops.gemm(x, f["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=f["b"],
+                 rowoff=tb["final"], seg_len=cin, heatmap=(K, hh * ww, self.temperature))
+        # ---- aux branches
+        a, ah, aw = feats, h, w
+        for i, (p, (ro, _, _)) in enumerate(zip(self.pools, tb["aux"])):
+            M = B * ah * aw
+            conv = g(f"aux_conv{i}", (M, 4 * C), dt, dev)
+            if i == 0:
+                ops.gemm(a, self.aux_w[0], conv, M=M, N=4 * C, Kd=9 * C, lda=C, ldw=9 * C, ldc=4 * C,
+                         bias=self.aux_b[0], rowoff=ro, seg_len=C)
+            else:
+                ops.gemm(a, self.aux_w[i], conv, M=M, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
+                         bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,
+                         strideC=C, strideBias=C)
+            kh, kw, oh, ow = pack.pool_out(ah, aw, p)
+            pooled = g(f"aux_pool{i}", (B * oh * ow, 4 * C), dt, dev)
+            ops.maxpool_relu(conv, pooled, B, ah, aw, 4 * C, kh, kw)
+            a, ah, aw = pooled, oh, ow
+        aux = torch.empty((4, B, K), dtype=torch.float32, device=dev)
+        ops.aux_tail(a, self.tail_w, self.tail_b, aux, B, C, K)
+        return (heat, aux[0].reshape(B, K, 1, 1), aux[1].reshape(B, K, 1, 1), aux[2].reshape(B, K, 1, 1),
+                aux[3].reshape(B, K, 1, 1))
+
+
+def build_head_plan(head, dtype, device):
+    return HeadPlan(head, dtype, device)

@@ -1,0 +1,112 @@
+"""Tensor-level wrappers over the C ABI (include/probpose_hip.h).
+
+Every function takes torch tensors that already live on the GPU, launches on
+torch's current stream and returns immediately (no sync, no hidden copies), so
+a whole forward can be captured into a HIP graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_OUT_F32, EPI_RELU, EPI_RESIDUAL,  # noqa: F401
+                   EPI_ROWBIAS, PP_BF16, PP_F32)
+
+_DT = {torch.float32: PP_F32, torch.bfloat16: PP_BF16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dt}") from None
+
+
+def _p(t):
+    return _lib.ptr(t)
+
+
+def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
+         rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
+         strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None):
+    """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h."""
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C = _p(A), _p(W), _p(out)
+    a.bias, a.residual, a.rowbias = _p(bias), _p(residual), _p(rowbias)
+    a.rowoff, a.out_rowmap = _p(rowoff), _p(out_rowmap)
+    a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc = M, N, Kd, lda, ldw, ldc
+    a.seg_len, a.rowbias_period, a.batch = seg_len, rowbias_period, batch
+    a.strideA, a.strideW, a.strideC, a.strideBias = strideA, strideW, strideC, strideBias
+    a.strideRowoff, a.strideRowmap = strideRowoff, strideRowmap
+    a.dtype = dtype_code(W.dtype)
+    if bias is not None:
+        epilogue |= EPI_BIAS
+    if residual is not None:
+        epilogue |= EPI_RESIDUAL
+    if rowbias is not None:
+        epilogue |= EPI_ROWBIAS
+    if heatmap is not None:
+        epilogue |= EPI_HEATMAP
+        a.hm_K, a.hm_HW, a.hm_temperature = heatmap
+    a.epilogue = epilogue
+    _lib.check(_lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()), "pp_gemm")
+    return out
+
+
+def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=None):
+    """x [M,K] @ w[N,K]^T (+bias, activation / fp32 residual add)."""
+    M, Kd = x.shape
+    N = w.shape[0]
+    if residual is not None or out_dtype == torch.float32:
+        epilogue |= EPI_OUT_F32
+    if out is None:
+        dt = torch.float32 if (epilogue & EPI_OUT_F32) else w.dtype
+        out = torch.empty((M, N), dtype=dt, device=x.device)
+    return gemm(x, w, out, M=M, N=N, Kd=Kd, lda=x.stride(0), ldw=w.stride(0), ldc=out.stride(0),
+                bias=bias, residual=residual, epilogue=epilogue)
+
+
+def layernorm(x, gamma, beta, eps, out):
+    rows, Cc = x.shape
+    _lib.check(_lib.lib().pp_layernorm(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(out),
+                                       dtype_code(out.dtype), _lib.stream_ptr()), "pp_layernorm")
+    return out
+
+
+def attention(qkv, out, B, N, heads, hd):
+    _lib.check(_lib.lib().pp_attention(_p(qkv), _p(out), B, N, heads, hd, dtype_code(qkv.dtype),
+                                       _lib.stream_ptr()), "pp_attention")
+    return out
+
+
+def patchify(x, out, patch):
+    B, _, H, W = x.shape
+    _lib.check(_lib.lib().pp_patchify(_p(x), _p(out), B, H, W, patch, dtype_code(out.dtype),
+                                      _lib.stream_ptr()), "pp_patchify")
+    return out
+
+
+def maxpool_relu(x, out, B, h, w, Cc, kh, kw):
+    _lib.check(_lib.lib().pp_maxpool_relu(_p(x), _p(out), B, h, w, Cc, kh, kw, dtype_code(x.dtype),
+                                          _lib.stream_ptr()), "pp_maxpool_relu")
+    return out
+
+
+def aux_tail(x, w, bias, out, B, Cc, K):
+    _lib.check(_lib.lib().pp_aux_tail(_p(x), _p(w), _p(bias), _p(out), B, Cc, K, dtype_code(w.dtype),
+                                      _lib.stream_ptr()), "pp_aux_tail")
+    return out
+
+
+def tokens_to_nchw(x, out, B, N, Cc):
+    _lib.check(_lib.lib().pp_tokens_to_nchw(_p(x), _p(out), B, N, Cc, dtype_code(x.dtype),
+                                            _lib.stream_ptr()), "pp_tokens_to_nchw")
+    return out
+
+
+def nchw_to_tokens(x, out, B, Cc, HW):
+    _lib.check(_lib.lib().pp_nchw_to_tokens(_p(x), _p(out), B, Cc, HW, dtype_code(out.dtype),
+                                            _lib.stream_ptr()), "pp_nchw_to_tokens")
+    return out

@@ -1,0 +1,119 @@
+"""End-to-end GPU parity of the forward path (backbone -> head -> decode)
+against the CPU oracle / the goldens minted from the reference.
+
+Staged parity claim ("bf16 vs 1e-4"):
+  (i)   decode kernel vs CPU decode on identical heatmaps: exact (test_decode_gpu.py)
+  (ii)  fp32 GPU forward vs CPU forward: <= 1e-4 abs on heatmaps / aux outputs,
+        and decoded keypoints <= 1e-4 px wherever the argmax is well separated
+  (iii) bf16: measured deviation is reported and loosely bounded.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import probpose_oracle as orc
+from tests.helpers import GOLDEN, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg(built_lib):
+    assert torch.cuda.is_available()
+    import probpose_pytorch_amd as p
+    from probpose_pytorch_amd import backbone, head, model, synthetic
+    return dict(p=p, backbone=backbone, head=head, model=model, syn=synthetic)
+
+
+def _build(pkg, img, C, depth, heads, K, pools, deconv=(256, 256), seed=0):
+    syn = pkg["syn"]
+    m = pkg["model"].ProbPoseModel(
+        pkg["backbone"].ScratchViTBackbone(img, 16, embed_dim=C, depth=depth, num_heads=heads),
+        pkg["head"].ProbMapHead(C, K, pools, deconv, (4,) * len(deconv), final_layer_kernel_size=1))
+    sd = syn.synthetic_model_state(img, 16, C, depth, K, len(pools), deconv, seed=seed)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), sd
+
+
+def test_head_fp32_matches_reference_golden(pkg):
+    """G3: HIP ProbMapHead vs the reference ProbMapHead outputs (fp32, atol 1e-4)."""
+    g = np.load(os.path.join(GOLDEN, "head_c384.npz"))
+    C, K = int(g["C"]), int(g["K"])
+    pools = [tuple(int(v) for v in p) for p in g["pools"]]
+    head = pkg["head"].ProbMapHead(C, K, pools, (256, 256), (4, 4), final_layer_kernel_size=1)
+    head.load_state_dict(pkg["syn"].synthetic_head_state(C, K, len(pools), (256, 256), seed=11))
+    head = head.cuda().eval()
+    feats = pkg["syn"].synthetic_features(2, C, 16, 12, seed=12)
+    assert sha(feats.numpy()) == str(g["feats_sha"])
+    out = head(feats.cuda())
+    assert out[0].shape == (2, K, 64, 48) and out[1].shape == (2, K, 1, 1) and out[0].dtype == torch.float32
+    for o, key in zip(out, ("heatmaps", "prob", "vis", "oks", "err")):
+        np.testing.assert_allclose(o.cpu().numpy(), g[key], rtol=0, atol=1e-4)
+    # G4: chained decode; the HIP decode of the HIP heatmaps equals the oracle decode of the same heatmaps
+    codec = pkg["p"].Codec(pkg["p"].ProbMap((192, 256), (48, 64), orc.COCO17_SIGMAS))
+    got = codec.decode(out)
+    want = orc.codec_decode([o.cpu().numpy() for o in out], (192, 256), (48, 64), orc.COCO17_SIGMAS)
+    np.testing.assert_array_equal(got[0][0], want[0][0])
+    np.testing.assert_array_equal(got[0][1], want[0][1])
+    # ... and agrees with the reference's decoded keypoints wherever fp32 reordering did not flip an argmax
+    close = np.abs(got[0][0] - g["kpts"]).max(-1) <= 1e-4
+    assert close.mean() >= 0.9, f"only {close.mean():.2%} of keypoints within 1e-4 px of the reference"
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(img=(64, 48), C=128, depth=2, heads=2, K=17, pools=[(4, 3)], deconv=(64, 64), B=3),
+    dict(img=(256, 192), C=384, depth=12, heads=12, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256), B=1),
+], ids=["tiny", "S1-vit-s-256x192"])
+def test_model_fp32_matches_cpu_oracle(pkg, cfg):
+    m, sd = _build(pkg, cfg["img"], cfg["C"], cfg["depth"], cfg["heads"], cfg["K"], cfg["pools"], cfg["deconv"])
+    x = pkg["syn"].synthetic_crops(cfg["B"], *cfg["img"], seed=1234)
+    with torch.no_grad():
+        want = orc.model_forward(sd, x, patch=16, heads=cfg["heads"], pools=cfg["pools"], n_deconv=len(cfg["deconv"]))
+        got = m(x.cuda())
+    # backbone alone, NCHW contract of backbone.py:35-40
+    feats = m.backbone(x.cuda())
+    want_f = orc.backbone_forward(sd, x, patch=16, heads=cfg["heads"], prefix="backbone.model.")
+    assert feats.shape == want_f.shape and feats.is_contiguous()
+    np.testing.assert_allclose(feats.cpu().numpy(), want_f.numpy(), rtol=0, atol=1e-4)
+    for gt, wt, name in zip(got, want, ("heatmaps", "prob", "vis", "oks", "err")):
+        assert gt.shape == wt.shape, name
+        np.testing.assert_allclose(gt.cpu().numpy(), wt.numpy(), rtol=0, atol=1e-4, err_msg=name)
+    H, W = cfg["img"]
+    codec = pkg["p"].Codec(pkg["p"].ProbMap((W, H), (W // 4, H // 4), orc.COCO17_SIGMAS))
+    dec = codec.decode(got)
+    ref = orc.codec_decode([w.numpy() for w in want], (W, H), (W // 4, H // 4), orc.COCO17_SIGMAS)
+    for a, b in zip(dec[1:4], ref[1:4]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(dec[4], ref[4], rtol=0, atol=1e-4)
+    d = np.abs(dec[0][0] - ref[0][0]).max(-1)
+    print(f"\n[{cfg['C']}] keypoints within 1e-4 px of the CPU path: {(d <= 1e-4).mean():.2%}, max {d.max():.3g}")
+    assert (d <= 1e-4).mean() >= 0.9
+
+
+def test_model_bf16_deviation_is_bounded_and_reported(pkg):
+    cfg = dict(img=(256, 192), C=384, depth=12, heads=6, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256))
+    m, sd = _build(pkg, cfg["img"], cfg["C"], cfg["depth"], cfg["heads"], cfg["K"], cfg["pools"], cfg["deconv"])
+    x = pkg["syn"].synthetic_crops(2, *cfg["img"], seed=1234)
+    with torch.no_grad():
+        want = orc.model_forward(sd, x, patch=16, heads=cfg["heads"], pools=cfg["pools"])
+        m.set_compute_dtype(torch.bfloat16)
+        got = m(x.cuda())
+    dh = (got[0].cpu() - want[0]).abs()
+    da = max((g.cpu() - w).abs().max().item() for g, w in zip(got[1:], want[1:]))
+    print(f"\nbf16 vs fp32 CPU: heatmap max|d| {dh.max():.4f} mean|d| {dh.mean():.5f}; aux max|d| {da:.4f}")
+    assert dh.mean() < 0.02 and da < 0.1
+
+
+def test_model_rebuilds_plan_when_weights_change(pkg):
+    m, sd = _build(pkg, (64, 48), 128, 1, 2, 5, [(4, 3)], (64,))
+    x = pkg["syn"].synthetic_crops(1, 64, 48).cuda()
+    a = m(x)[0].clone()
+    with torch.no_grad():
+        m.head.final_layer.bias.add_(0.25)
+    b = m(x)[0]
+    assert not torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        m.head.train()
+        m(x)

@@ -1,0 +1,225 @@
+"""GPU numerics of every HIP kernel on the forward path against a plain
+PyTorch reference of the same op (float64 math on the same inputs).
+
+fp32 mode uses v_mfma_f32_16x16x4_f32 (an exact fp32 FMA chain): tolerance
+~1e-5 relative.  bf16 mode: operands are bf16 (the reference is computed from
+the same bf16-rounded operands), fp32 accumulate; an fp32 output is held to
+1e-4 relative of the operand scale, a bf16 output to one bf16 ulp (2^-8)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops(built_lib):
+    assert torch.cuda.is_available()
+    from probpose_pytorch_amd import ops as o
+    return o
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _tol(dtype, out_dtype):
+    if dtype == torch.float32:
+        return dict(rtol=2e-5, atol=2e-5)
+    if out_dtype == torch.float32:
+        return dict(rtol=1e-4, atol=1e-3)
+    return dict(rtol=2 ** -7, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 768, 768), (300, 200, 128), (1, 17, 256), (257, 129, 64),
+                                   (384, 2304, 768)])
+def test_gemm_plain_bias_tails(ops, dtype, M, N, K):
+    A, W = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, K ** -0.5)
+    b = _rand((N,), torch.float32, 3)
+    out = ops.linear(A, W, b)
+    ref = A.double() @ W.double().t() + b.double()
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype, dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 384, 256, 256
+    A, W = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, K ** -0.5)
+    b = _rand((N,), torch.float32, 3)
+    pre = A.double() @ W.double().t() + b.double()
+    out = ops.linear(A, W, b, epilogue=ops.EPI_GELU)
+    torch.testing.assert_close(out.double(), F.gelu(pre), **_tol(dtype, dtype))
+    out = ops.linear(A, W, b, epilogue=ops.EPI_RELU)
+    torch.testing.assert_close(out.double(), F.relu(pre), **_tol(dtype, dtype))
+    res = _rand((M, N), torch.float32, 4)
+    want = res.double() + pre
+    ops.linear(A, W, b, out=res, residual=res)                 # in place on the fp32 residual stream
+    torch.testing.assert_close(res.double(), want, **_tol(dtype, torch.float32))
+    # row bias with period (pos_embed): out[m] += rb[m % P]
+    P = 96
+    rb = _rand((P, N), torch.float32, 5)
+    out = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    ops.gemm(A, W, out, M=M, N=N, Kd=K, lda=K, ldw=K, ldc=N, bias=b, rowbias=rb, rowbias_period=P,
+             epilogue=ops.EPI_OUT_F32)
+    want = pre + rb.double().repeat(M // P, 1)
+    torch.testing.assert_close(out.double(), want, **_tol(dtype, torch.float32))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_exact_integer_data_catches_layout_bugs(ops, dtype):
+    """A = I-like / asymmetric small-integer operands: exact in both dtypes."""
+    M, N, K = 256, 256, 128
+    g = torch.Generator().manual_seed(0)
+    A = torch.randint(-3, 4, (M, K), generator=g).to(dtype).cuda()
+    W = torch.randint(-3, 4, (N, K), generator=g).to(dtype).cuda()
+    out = ops.linear(A, W, out_dtype=torch.float32)
+    assert torch.equal(out.double(), A.double() @ W.double().t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_conv3x3_gather_batched_branches(ops, dtype):
+    """Aux-branch stage >= 1: 4 branches, each a 3x3 conv on its C-wide slice of 4C-wide rows."""
+    from probpose_pytorch_amd import pack
+    B, h, w, C = 3, 4, 4, 64
+    x = _rand((B * h * w, 4 * C), dtype, 1)
+    wt = _rand((4, C, C, 3, 3), torch.float32, 2, (9 * C) ** -0.5)
+    bias = _rand((4, C), torch.float32, 3)
+    Wp = torch.stack([pack.conv_taps_major(wt[i].cpu()) for i in range(4)]).to(dtype).cuda()
+    ro = pack.conv_gather_table(B, h, w, 3, 3, 1, 1, 4 * C).cuda()
+    out = torch.empty((B * h * w, 4 * C), dtype=dtype, device="cuda")
+    ops.gemm(x, Wp, out, M=B * h * w, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C, bias=bias, rowoff=ro,
+             seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C, strideBias=C)
+    for i in range(4):
+        xi = x[:, i * C:(i + 1) * C].double().reshape(B, h, w, C).permute(0, 3, 1, 2)
+        wi = Wp[i].double().reshape(C, 3, 3, C).permute(0, 3, 1, 2)
+        ref = F.conv2d(xi, wi, bias[i].double(), padding=1).permute(0, 2, 3, 1).reshape(B * h * w, C)
+        torch.testing.assert_close(out[:, i * C:(i + 1) * C].double(), ref, **_tol(dtype, dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [4, 3, 2])
+def test_gemm_deconv_parities_scatter(ops, dtype, k):
+    from probpose_pytorch_amd import pack
+    B, h, w, Cin, Cout = 2, 8, 6, 64, 128
+    x = _rand((B * h * w, Cin), dtype, 1)
+    wt = _rand((Cin, Cout, k, k), torch.float32, 2, (4 * Cin) ** -0.5)
+    bias = _rand((Cout,), torch.float32, 3)
+    Wp = pack.pack_deconv_parities(wt.cpu(), k).to(dtype).cuda()
+    ro, rm = pack.deconv_tables(B, h, w, k, Cin)
+    M = B * h * w
+    out = torch.full((4 * M, Cout), float("nan"), dtype=dtype, device="cuda")
+    ops.gemm(x, Wp, out, M=M, N=Cout, Kd=4 * Cin, lda=Cin, ldw=4 * Cin, ldc=Cout, bias=bias, rowoff=ro.cuda(),
+             seg_len=Cin, out_rowmap=rm.cuda(), batch=4, strideW=Cout * 4 * Cin, strideRowoff=4 * M,
+             strideRowmap=M, epilogue=ops.EPI_RELU)
+    pad, op = pack.deconv_geometry(k)
+    # reference from the same (rounded) packed weights: rebuild the deconv weight from Wp
+    xi = x.double().reshape(B, h, w, Cin).permute(0, 3, 1, 2)
+    wr = wt.to(dtype).double()
+    ref = F.relu(F.conv_transpose2d(xi, wr, bias.double(), stride=2, padding=pad, output_padding=op))
+    ref = ref.permute(0, 2, 3, 1).reshape(4 * M, Cout)
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype, dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_heatmap_epilogue(ops, dtype):
+    B, HW, Cin, K = 2, 64 * 48, 256, 17
+    x = _rand((B * HW, Cin), dtype, 1)
+    W = _rand((K, Cin), dtype, 2, Cin ** -0.5)
+    b = _rand((K,), torch.float32, 3, 0.1)
+    out = torch.empty((B, K, HW), dtype=torch.float32, device="cuda")
+    ops.gemm(x, W, out, M=B * HW, N=K, Kd=Cin, lda=Cin, ldw=Cin, ldc=K, bias=b, heatmap=(K, HW, 0.5))
+    pre = (x.double() @ W.double().t() + b.double()).reshape(B, HW, K).permute(0, 2, 1)
+    ref = torch.clamp(pre / 0.5, 0, 1)
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype, torch.float32))
+    assert out.min() == 0 and out.max() == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(384, 768), (5, 384), (64, 1280), (3, 100), (2, 4096)])
+def test_layernorm(ops, dtype, rows, C):
+    x = _rand((rows, C), torch.float32, 1, 3.0) + 0.5
+    g, b = _rand((C,), torch.float32, 2), _rand((C,), torch.float32, 3)
+    out = torch.empty((rows, C), dtype=dtype, device="cuda")
+    ops.layernorm(x, g, b, 1e-6, out)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-6)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2 ** -7, atol=2e-2)
+    torch.testing.assert_close(out.double(), ref, **tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 192, 12, 64), (1, 192, 12, 32), (2, 432, 2, 80), (3, 12, 2, 64),
+                                          (1, 70, 3, 32)])
+def test_attention(ops, dtype, B, N, heads, hd):
+    C = heads * hd
+    qkv = _rand((B * N, 3 * C), dtype, 1)
+    out = torch.empty((B * N, C), dtype=dtype, device="cuda")
+    ops.attention(qkv, out, B, N, heads, hd)
+    q, k, v = qkv.double().reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * N, C)
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2 ** -6, atol=2e-2)
+    torch.testing.assert_close(out.double(), ref, **tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_patchify(ops, dtype):
+    B, H, W, p = 2, 64, 48, 16
+    x = torch.rand((B, 3, H, W), generator=torch.Generator().manual_seed(0)).cuda()
+    out = torch.empty((B * (H // p) * (W // p), 3 * p * p), dtype=dtype, device="cuda")
+    ops.patchify(x, out, p)
+    ref = F.unfold(x, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p)   # k = c*p*p + py*p + px
+    assert torch.equal(out, ref.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("h,w,kh,kw", [(16, 12, 4, 3), (4, 4, 2, 2), (2, 2, 2, 2), (24, 18, 4, 3), (6, 6, 3, 3), (5, 5, 2, 2)])
+def test_maxpool_relu(ops, dtype, h, w, kh, kw):
+    B, C = 2, 64
+    x = _rand((B * h * w, C), dtype, 1)
+    out = torch.empty((B * (h // kh) * (w // kw), C), dtype=dtype, device="cuda")
+    ops.maxpool_relu(x, out, B, h, w, C, kh, kw)
+    xi = x.float().reshape(B, h, w, C).permute(0, 3, 1, 2)
+    ref = F.relu(F.max_pool2d(xi, (kh, kw))).permute(0, 2, 3, 1).reshape(-1, C)
+    assert torch.equal(out.float(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_aux_tail(ops, dtype):
+    B, C, K = 5, 384, 17
+    x = _rand((B, 4 * C), dtype, 1)
+    w = _rand((4, K, C), dtype, 2, C ** -0.5)
+    b = _rand((4, K), torch.float32, 3)
+    out = torch.empty((4, B, K), dtype=torch.float32, device="cuda")
+    ops.aux_tail(x, w, b, out, B, C, K)
+    for i in range(4):
+        pre = x[:, i * C:(i + 1) * C].double() @ w[i].double().t() + b[i].double()
+        ref = torch.sigmoid(pre) if i < 3 else F.relu(pre)
+        torch.testing.assert_close(out[i].double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_transposes(ops, dtype):
+    B, N, C = 3, 192, 100
+    t = _rand((B * N, C), dtype, 1)
+    out = torch.empty((B, C, N), dtype=torch.float32, device="cuda")
+    ops.tokens_to_nchw(t, out, B, N, C)
+    assert torch.equal(out, t.float().reshape(B, N, C).permute(0, 2, 1))
+    back = torch.empty((B * N, C), dtype=dtype, device="cuda")
+    ops.nchw_to_tokens(out, back, B, C, N)
+    assert torch.equal(back, t)
+
+
+def test_bad_arguments_raise(ops):
+    from probpose_pytorch_amd import _lib
+    A = torch.zeros((128, 40), device="cuda")
+    W = torch.zeros((128, 40), device="cuda")
+    with pytest.raises(_lib.HipExtensionError, match="multiple"):
+        ops.linear(A, W)                       # K not a multiple of the tile depth
+    with pytest.raises(_lib.HipExtensionError, match="head_dim"):
+        ops.attention(torch.zeros((4, 3 * 48), device="cuda"), torch.zeros((4, 48), device="cuda"), 1, 4, 1, 48)
+    with pytest.raises(TypeError):
+        ops.linear(A.half(), W.half())
