@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Headline benchmark: person-crops/sec (+ decode ms) of the ProbPose forward +
+decode path, ViT-B 256x192 K=17 bf16, batch 64 per MI355X (BASELINE.json
+configs[1]).  One process per GPU; for N > 1 launch with torch.distributed.run
+(rank r takes crops [r*64, (r+1)*64) of the global batch, weak scaling) and the
+decoded keypoints are all-gathered over RCCL every step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+
+Prints ONE JSON line on rank 0.  A step = patchify -> ViT -> ProbMapHead ->
+fused decode (-> all-gather), inputs resident in HBM, synthetic crops and
+seeded random-init weights (no network for datasets/checkpoints).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CONFIGS = {
+    # name: (embed_dim, depth, heads, img (H,W), K, pools, per-GPU batch)
+    "vit_s": dict(C=384, depth=12, heads=12, img=(256, 192), K=17, pools=[(4, 3), (2, 2), (2, 2)], batch=64),
+    "vit_b": dict(C=768, depth=12, heads=12, img=(256, 192), K=17, pools=[(4, 3), (2, 2), (2, 2)], batch=64),
+    "vit_l": dict(C=1024, depth=24, heads=16, img=(256, 192), K=17, pools=[(4, 3), (2, 2), (2, 2)], batch=256),
+    "vit_h_wholebody": dict(C=1280, depth=32, heads=16, img=(384, 288), K=133, pools=[(4, 3), (2, 2), (3, 3)],
+                            batch=128),
+}
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 (MI355X_MICROARCH.md: ~2.5 PF dense)
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0
+
+
+def flops_per_crop(cfg) -> float:
+    """Algorithmic forward FLOPs (2*MAC) per crop, SURVEY.md section 8d formulae."""
+    C, depth, (H, W), K = cfg["C"], cfg["depth"], cfg["img"], cfg["K"]
+    gh, gw = H // 16, W // 16
+    N = gh * gw
+    patch = 2 * 768 * C * N
+    blocks = depth * (N * 24 * C * C + 4 * N * N * C)
+    deconv = 2 * gh * gw * C * 256 * 16 + 2 * (2 * gh) * (2 * gw) * 256 * 256 * 16
+    final = 2 * (4 * gh) * (4 * gw) * 256 * K
+    aux, h, w = 0, gh, gw
+    for p in cfg["pools"]:
+        aux += 2 * h * w * 9 * C * C
+        h, w = h // p[0], w // p[1]
+    aux = 4 * (aux + 2 * C * K)
+    return float(patch + blocks + deconv + final + aux)
+
+
+def sigmas_for(K: int) -> np.ndarray:
+    from probpose_pytorch_amd.synthetic import torch as _t  # noqa: F401
+    if K == 17:
+        return np.array([.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087, .087,
+                         .089, .089])
+    return np.random.default_rng(133).uniform(0.02, 0.11, K)
+
+
+def build(cfg, dtype, device):
+    from probpose_pytorch_amd import Codec, ProbMap
+    from probpose_pytorch_amd.backbone import ScratchViTBackbone
+    from probpose_pytorch_amd.head import ProbMapHead
+    from probpose_pytorch_amd.model import ProbPoseModel
+    from probpose_pytorch_amd.synthetic import synthetic_model_state
+    H, W = cfg["img"]
+    model = ProbPoseModel(ScratchViTBackbone((H, W), 16, embed_dim=cfg["C"], depth=cfg["depth"], num_heads=cfg["heads"]),
+                          ProbMapHead(cfg["C"], cfg["K"], cfg["pools"], (256, 256), (4, 4), final_layer_kernel_size=1))
+    sd = synthetic_model_state((H, W), 16, cfg["C"], cfg["depth"], cfg["K"], len(cfg["pools"]), (256, 256), seed=0)
+    model.load_state_dict(sd)
+    model = model.to(device).eval().set_compute_dtype(dtype)
+    codec = Codec(ProbMap((W, H), (W // 4, H // 4), sigmas_for(cfg["K"])))
+    return model, codec, sd
+
+
+def cpu_baseline(cfg, sd, seconds_budget: float = 20.0):
+    """The reference's CPU path (restated in oracle/, pinned on the reference's goldens): plain PyTorch
+    fp32 eval forward + per-crop scipy decode, timed on this host's cores on a bounded sample."""
+    from oracle import probpose_oracle as orc
+    from probpose_pytorch_amd.synthetic import synthetic_crops
+    H, W = cfg["img"]
+    cores = torch.get_num_threads()
+    sig = sigmas_for(cfg["K"])
+
+    def run(x):
+        with torch.no_grad():
+            out = orc.model_forward(sd, x, patch=16, heads=cfg["heads"], pools=cfg["pools"])
+        return orc.codec_decode([o.numpy() for o in out], (W, H), (W // 4, H // 4), sig)
+
+    x1 = synthetic_crops(2, H, W, seed=99)
+    t0 = time.perf_counter()
+    run(x1)                                   # warm-up + calibration
+    per_crop = (time.perf_counter() - t0) / 2
+    n = int(max(2, min(64, seconds_budget / max(per_crop, 1e-3))))
+    x = synthetic_crops(n, H, W, seed=1234)
+    t0 = time.perf_counter()
+    out = run(x)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        hm = orc.model_forward(sd, x[:2], patch=16, heads=cfg["heads"], pools=cfg["pools"])
+    fwd2 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.codec_decode([o.numpy() for o in hm], (W, H), (W // 4, H // 4), sig)
+    dec_ms = (time.perf_counter() - t0) / 2 * 1e3
+    return {"value": round(n / dt, 3), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"{n} crops, torch fp32 CPU eval forward + per-crop scipy decode (oracle/probpose_oracle.py), "
+                      f"one pass after a 2-crop warm-up", "decode_ms_per_crop": round(dec_ms, 3),
+            "forward_ms_per_crop": round(fwd2 / 2 * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="vit_b", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from probpose_pytorch_amd import ops, parallel
+    from probpose_pytorch_amd.synthetic import synthetic_crops
+
+    cfg = dict(CONFIGS[args.config])
+    if args.batch:
+        cfg["batch"] = args.batch
+    B = cfg["batch"]
+    H, W = cfg["img"]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model, codec, sd = build(cfg, dtype, device)
+    x = synthetic_crops(B, H, W, seed=1234 + rank).to(device)       # resident in HBM before timing
+
+    def local_step():
+        out = model(x)
+        dec = codec.decode_device(out)
+        return parallel.pack_decoded(dec)
+
+    def step(fn):
+        packed = fn()
+        return parallel.all_gather_decoded(packed) if world > 1 else packed
+
+    # ---- warm-up (also builds plans, tables, tap caches), then optional graph capture
+    with torch.no_grad():
+        for _ in range(max(1, min(2, args.warmup))):
+            step(local_step)
+        torch.cuda.synchronize()
+        graph, static_out = None, None
+        if not args.no_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                local_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = local_step()
+
+            def replay():
+                graph.replay()
+                return static_out
+            run_local = replay
+        else:
+            run_local = local_step
+        for _ in range(args.warmup):
+            step(run_local)
+
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            result = step(run_local)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert result.shape == (B * world, cfg["K"], 7)
+
+        # ---- kernel-level timing with HIP events on the launch stream (eager pass, same inputs)
+        prof = []
+        ops.set_profile(prof)
+        for _ in range(3):
+            local_step()
+        torch.cuda.synchronize()
+        ops.set_profile(None)
+    agg = {}
+    for name, work, s, e in prof:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += work
+        a[2] += s.elapsed_time(e) * 1e-3
+    per_step = {k: (v[0] / 3, v[1] / 3, v[2] / 3) for k, v in agg.items()}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    crops_per_s = B * world * args.steps / elapsed
+    if rank == 0:
+        g_n, g_flops, g_t = per_step.get("gemm", (0, 0.0, 1.0))
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        achieved = g_flops / g_t / 1e12
+        d_n, d_bytes, d_t = per_step.get("decode", (0, 0.0, 1.0))
+        a_n, a_flops, a_t = per_step.get("attention", (0, 0.0, 1.0))
+        line = {
+            "metric": "person_crops_per_sec", "value": round(crops_per_s, 2), "unit": "crops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"ProbPose forward+decode, {args.config} {H}x{W} K={cfg['K']}, "
+                                   f"batch {B}/GPU, {'HIP graph replay' if graph is not None else 'eager launches'}",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "gflop_per_crop": round(flops_per_crop(cfg) / 1e9, 2)},
+            "decode_ms": round(d_t * 1e3, 4),
+            "model_tflops": round(flops_per_crop(cfg) * crops_per_s / world / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel", "achieved": round(achieved, 2), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
+                         "flop_per_launch": round(g_flops / max(g_n, 1), 0)},
+            "roofline_decode": {"bound": "hbm", "kernel": "pp::decode_lds_kernel",
+                                "achieved": round(d_bytes / d_t / 1e9, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                "frac": round(d_bytes / d_t / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                                "bytes_per_launch": d_bytes},
+            "attention": {"achieved_tflops": round(a_flops / a_t / 1e12, 2), "ms_per_step": round(a_t * 1e3, 3)},
+            "kernel_ms_per_step": {k: round(v[2] * 1e3, 3) for k, v in per_step.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,13 +93,14 @@ def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=Non
         out["conv"] = torch.empty_like(heatmaps)
     ws_bytes = L.pp_decode_workspace_bytes(B, K, H, W)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+    from . import ops as _ops
     with torch.cuda.device(dev):
-        rc = L.pp_decode_f32(
+        rc = _ops._timed("decode", float(B * K * (H * W * 4 + 16 + 28)), lambda: L.pp_decode_f32(
             _lib.ptr(heatmaps), _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]),
             B, K, H, W, _lib.ptr(taps), _lib.ptr(radius), den_x, den_y, in_w, in_h,
             _lib.ptr(out.get("kpts")), _lib.ptr(out["scores"]), _lib.ptr(out["locs"]),
             _lib.ptr(out.get("aux")), _lib.ptr(out.get("err")), _lib.ptr(out.get("conv")),
-            _lib.ptr(ws), _lib.stream_ptr())
+            _lib.ptr(ws), _lib.stream_ptr()))
     _lib.check(rc, "pp_decode_f32")
     return out
 

@@ -17,6 +17,26 @@ from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_OUT_F32, EPI_RELU, EPI_R
 _DT = {torch.float32: PP_F32, torch.bfloat16: PP_BF16}
 
 
+_PROFILE = None  # bench.py's kernel-level timing hook: list of (name, work, start_event, end_event)
+
+
+def set_profile(sink):
+    """sink = list to append (name, algorithmic_work, start, end) records to, or None to disable."""
+    global _PROFILE
+    _PROFILE = sink
+
+
+def _timed(name, work, fn):
+    if _PROFILE is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _PROFILE.append((name, work, s, e))
+    return r
+
+
 def dtype_code(dt: torch.dtype) -> int:
     try:
         return _DT[dt]
@@ -51,7 +71,8 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         epilogue |= EPI_HEATMAP
         a.hm_K, a.hm_HW, a.hm_temperature = heatmap
     a.epilogue = epilogue
-    _lib.check(_lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()), "pp_gemm")
+    rc = _timed("gemm", 2.0 * M * N * Kd * batch, lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()))
+    _lib.check(rc, "pp_gemm")
     return out
 
 
@@ -70,14 +91,18 @@ def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=No
 
 def layernorm(x, gamma, beta, eps, out):
     rows, Cc = x.shape
-    _lib.check(_lib.lib().pp_layernorm(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(out),
-                                       dtype_code(out.dtype), _lib.stream_ptr()), "pp_layernorm")
+    rc = _timed("layernorm", float(rows * Cc * (4 + out.element_size())),
+                lambda: _lib.lib().pp_layernorm(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(out),
+                                                dtype_code(out.dtype), _lib.stream_ptr()))
+    _lib.check(rc, "pp_layernorm")
     return out
 
 
 def attention(qkv, out, B, N, heads, hd):
-    _lib.check(_lib.lib().pp_attention(_p(qkv), _p(out), B, N, heads, hd, dtype_code(qkv.dtype),
-                                       _lib.stream_ptr()), "pp_attention")
+    rc = _timed("attention", 4.0 * B * heads * N * N * hd,
+                lambda: _lib.lib().pp_attention(_p(qkv), _p(out), B, N, heads, hd, dtype_code(qkv.dtype),
+                                                _lib.stream_ptr()))
+    _lib.check(rc, "pp_attention")
     return out
 
 
