@@ -47,13 +47,37 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
-__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+// LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte offset (M0) + lane * 16.  Issued
+// from inline asm on purpose: hipcc cannot tell that the DMA into buffer t+1 never aliases the
+// ds_reads of buffer t and would drain vmcnt(0) in front of every fragment read, serialising the
+// prefetch behind the MFMAs.  The asm DMA is invisible to its wait-count bookkeeping; completion is
+// enforced by the explicit s_waitcnt vmcnt(0) + barrier that ends each K-step.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_off_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_off_uniform)
+      : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_offset_of(const void *p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below a bf16 ulp): bf16 epilogues only.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erfz = 1.0f - poly * t * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erfz, x));
 }
 
 template <typename T>
@@ -99,20 +123,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   const int lchunk_off = (pchunk ^ prow) * 16;  // (row & 7) == prow for every piece
   const int nkt = p.Kd / BK;
 
+  const unsigned lds0 = lds_offset_of(smem);
+  // gather mode: the row offsets of a K-segment (one convolution tap) stay in registers for the
+  // whole segment and the next segment's are fetched one K-tile ahead, so the dependent
+  // table-load -> DMA-address chain never sits on the critical path.
+  int cur_off[4] = {0, 0, 0, 0}, nxt_off[4] = {0, 0, 0, 0};
+  if (rowoff) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cur_off[j] = rowoff[a_row[j]];
+  }
   auto stage = [&](int kt, int buf) {
-    char *ldsA = smem + buf * 2 * TILE_BYTES + wave * 4 * 1024;
-    char *ldsB = ldsA + TILE_BYTES;
+    const unsigned ldsA =
+        __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * TILE_BYTES + wave * 4 * 1024);
+    const unsigned ldsB = ldsA + TILE_BYTES;
     const size_t koff = (size_t)kt * ROW_BYTES;
     if (rowoff) {
       const int k0 = kt * BK;
       const int seg = k0 / p.seg_len;
       const int kin = k0 - seg * p.seg_len;
+      if (kin == 0 && kt > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur_off[j] = nxt_off[j];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int off = rowoff[(size_t)seg * p.M + a_row[j]];
-        const char *src = off >= 0 ? Ab + ((size_t)off + kin) * ES + lchunk_off
-                                   : (const char *)g_zero_page + lchunk_off;
+        const char *src = cur_off[j] >= 0 ? Ab + ((size_t)cur_off[j] + kin) * ES + lchunk_off
+                                          : (const char *)g_zero_page + lchunk_off;
         glds16(src, ldsA + j * 1024);
+      }
+      if (kin + BK == p.seg_len && k0 + BK < p.Kd) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nxt_off[j] = rowoff[(size_t)(seg + 1) * p.M + a_row[j]];
       }
     } else {
 #pragma unroll
@@ -150,7 +191,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                *reinterpret_cast<bf16x8 *>(&af[i]), *reinterpret_cast<bf16x8 *>(&bf[j]), acc[i][j], 0, 0, 0);
+                *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
       } else {
         // fp32: the chunk holds 4 consecutive k; MFMA step e takes element e of every lane's
         // chunk (k slots 16s + 4*fq + e, the same permutation on both operands).
@@ -161,8 +202,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                  __uint_as_float(reinterpret_cast<const unsigned *>(&af[i])[e]),
-                  __uint_as_float(reinterpret_cast<const unsigned *>(&bf[j])[e]), acc[i][j], 0, 0, 0);
+                  __uint_as_float(reinterpret_cast<const unsigned *>(&bf[j])[e]),
+                  __uint_as_float(reinterpret_cast<const unsigned *>(&af[i])[e]), acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -181,41 +222,80 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   }
   compute(cur);
 
-  // ---- epilogue.  16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  // ---- epilogue.  The W fragment is the MFMA "A" operand and the activation fragment the "B"
+  // operand, so a 16x16 accumulator tile holds C^T: lane (frow, fq) owns output row m = .. + frow and
+  // the 4 CONSECUTIVE columns n = .. + 4*fq + e -> 8-byte (bf16) / 16-byte (fp32) vector stores.
   const int epi = p.epilogue;
   const float *bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const int32_t *rowmap = p.out_rowmap ? p.out_rowmap + (size_t)z * p.strideRowmap : nullptr;
   char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
   const float *Rb = p.residual ? p.residual + (size_t)z * p.strideC : nullptr;
+  const bool vec_ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && !(epi & PP_EPI_HEATMAP);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int mbase = m0 + wm * 64 + i * 16 + fq * 4;
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+    const int r = rowmap ? rowmap[m] : m;
+    const float *rb = (epi & PP_EPI_ROWBIAS) ? p.rowbias + (size_t)(m % p.rowbias_period) * p.ldc : nullptr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + frow;
+      const int n = n0 + wn * 64 + j * 16 + fq * 4;
       if (n >= p.N) continue;
-      const float bn = (epi & PP_EPI_BIAS) ? bias[n] : 0.f;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (vec_ok) {
+        if (epi & PP_EPI_BIAS) {
+          const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (rb) {
+          const float4 b4 = *reinterpret_cast<const float4 *>(rb + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (epi & PP_EPI_GELU) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int m = mbase + e;
-        if (m >= p.M) continue;
-        float v = acc[i][j][e] + bn;
-        if (epi & PP_EPI_ROWBIAS) v += p.rowbias[(size_t)(m % p.rowbias_period) * p.ldc + n];
-        if (epi & PP_EPI_GELU) v = gelu_erf(v);
-        if (epi & PP_EPI_RELU) v = fmaxf(v, 0.f);
-        const int r = rowmap ? rowmap[m] : m;
-        if (epi & PP_EPI_HEATMAP) {
-          v = fminf(fmaxf(v / p.hm_temperature, 0.f), 1.f);
-          const int b = r / p.hm_HW, hw = r - b * p.hm_HW;
-          reinterpret_cast<float *>(Cb)[((size_t)b * p.hm_K + n) * p.hm_HW + hw] = v;
-          continue;
+          for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
+        }
+        if (epi & PP_EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         const size_t idx = (size_t)r * p.ldc + n;
-        if (epi & PP_EPI_RESIDUAL) v += Rb[idx];
+        if (epi & PP_EPI_RESIDUAL) {
+          const float4 r4 = *reinterpret_cast<const float4 *>(Rb + idx);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+        }
+        if ((epi & PP_EPI_OUT_F32) || sizeof(T) == 4) {
+          *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Cb) + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(Cb) + idx) = pk;
+        }
+        continue;
+      }
+      // scalar path: ragged N (e.g. the K=17 heatmap layer) or unaligned ldc
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ne = n + e;
+        if (ne >= p.N) continue;
+        float x = v[e];
+        if (epi & PP_EPI_BIAS) x += bias[ne];
+        if (rb) x += rb[ne];
+        if (epi & PP_EPI_GELU) x = (sizeof(T) == 2) ? gelu_fast(x) : gelu_erf(x);
+        if (epi & PP_EPI_RELU) x = fmaxf(x, 0.f);
+        if (epi & PP_EPI_HEATMAP) {
+          x = fminf(fmaxf(x / p.hm_temperature, 0.f), 1.f);
+          const int b = r / p.hm_HW, hw = r - b * p.hm_HW;
+          reinterpret_cast<float *>(Cb)[((size_t)b * p.hm_K + ne) * p.hm_HW + hw] = x;
+          continue;
+        }
+        const size_t idx = (size_t)r * p.ldc + ne;
+        if (epi & PP_EPI_RESIDUAL) x += Rb[idx];
         if (epi & PP_EPI_OUT_F32)
-          reinterpret_cast<float *>(Cb)[idx] = v;
+          reinterpret_cast<float *>(Cb)[idx] = x;
         else
-          Store<T>::st(reinterpret_cast<T *>(Cb) + idx, v);
+          Store<T>::st(reinterpret_cast<T *>(Cb) + idx, x);
       }
     }
   }
