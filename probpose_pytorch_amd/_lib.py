@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
         ("strideA", C.c_longlong), ("strideW", C.c_longlong), ("strideC", C.c_longlong),
         ("strideBias", C.c_longlong), ("strideRowoff", C.c_longlong), ("strideRowmap", C.c_longlong),
         ("dtype", C.c_int), ("epilogue", C.c_int),
-        ("hm_K", C.c_int), ("hm_HW", C.c_int), ("hm_temperature", C.c_float),
+        ("hm_K", C.c_int), ("hm_HW", C.c_int), ("hm_temperature", C.c_float), ("tile", C.c_int),
     ]
 
 

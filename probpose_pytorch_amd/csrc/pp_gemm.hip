@@ -6,8 +6,11 @@
 // A rows optionally addressed through a gather table (implicit GEMM, no im2col
 // buffer), C rows optionally scattered through a row map.
 //
-// Structure (CDNA4): 128x128 output tile per 256-thread workgroup (4 waves as
-// 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles), K-tiles of 128 B per row
+// Structure (CDNA4): BM x BN output tile per 256-thread workgroup (4 waves as
+// 2x2, each (BM/2)x(BN/2) = TMxTN MFMA 16x16 tiles), two instantiations:
+// 192x96 (one crop's 192 tokens per M-tile: at B = 64 the four ViT GEMMs are
+// exactly 1/3/4/1 rounds of 512 resident workgroups, no tail) and 128x128;
+// K-tiles of 128 B per row
 // (64 bf16 / 32 fp32) staged HBM->LDS by global_load_lds_dwordx4 (no VGPR
 // round trip) into a double buffer, XOR-swizzled on the SOURCE address so the
 // LDS image stays lane-linear for the DMA while ds_read_b128 fragment reads
@@ -20,11 +23,9 @@ namespace pp {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128;
 constexpr int ROW_BYTES = 128;                 // bytes of K per staged row
-constexpr int TILE_BYTES = BM * ROW_BYTES;     // 16 KiB per operand per buffer
 constexpr int GEMM_THREADS = 256;
-constexpr int GEMM_LDS = 4 * TILE_BYTES;       // A0 B0 A1 B1 = 64 KiB
+constexpr int gemm_lds_bytes(int BM, int BN) { return 2 * (BM + BN) * ROW_BYTES; }  // double buffer
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -80,11 +81,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erfz, x));
 }
 
-template <typename T>
+template <typename T, int BM, int BN>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = ROW_BYTES / ES;  // elements of K per tile
+  constexpr int PA = BM / 32, PB = BN / 32;      // 1-KiB DMA pieces (8 rows) per wave per K-tile
+  constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 MFMA tiles per wave: (BM/2)/16 x (BN/2)/16
+  constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
 
   // ---- tile assignment: XCD-aware remap (blocks b, b+8 share an XCD/L2) so
   // the tiles sharing one A row-panel run on one XCD back to back.
@@ -104,21 +108,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
-  // ---- staging geometry: each wave issues 4 A + 4 B DMA pieces (8 rows x 128 B) per K-tile.
+  // ---- staging geometry: each wave issues PA A-pieces + PB W-pieces (8 rows x 128 B) per K-tile.
   // lane -> (row in piece, physical 16-B chunk); logical chunk = physical ^ (row & 7).
   const int prow = lane >> 3, pchunk = lane & 7;
-  int a_row[4], w_row[4];
-  const char *a_src[4];
-  const char *w_src[4];
+  int a_row[PA], w_row[PB];
+  const char *a_src[PA];
+  const char *w_src[PB];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + prow;  // row inside the 128-row tile
-    const int lchunk = pchunk ^ (r & 7);
-    a_row[j] = min(m0 + r, p.M - 1);          // tail rows re-read the last row (never stored)
+  for (int j = 0; j < PA; ++j) {
+    const int r = (wave * PA + j) * 8 + prow;  // row inside the BM-row tile
+    a_row[j] = min(m0 + r, p.M - 1);           // tail rows re-read the last row (never stored)
+    a_src[j] = Ab + (size_t)a_row[j] * p.lda * ES + (pchunk ^ prow) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int r = (wave * PB + j) * 8 + prow;
     w_row[j] = n0 + r;
-    a_src[j] = Ab + (size_t)a_row[j] * p.lda * ES + lchunk * 16;
-    w_src[j] = (w_row[j] < p.N) ? Wb + (size_t)w_row[j] * p.ldw * ES + lchunk * 16
-                                : (const char *)g_zero_page + lchunk * 16;
+    w_src[j] = (w_row[j] < p.N) ? Wb + (size_t)w_row[j] * p.ldw * ES + (pchunk ^ prow) * 16
+                                : (const char *)g_zero_page + (pchunk ^ prow) * 16;
   }
   const int lchunk_off = (pchunk ^ prow) * 16;  // (row & 7) == prow for every piece
   const int nkt = p.Kd / BK;
@@ -127,15 +134,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   // gather mode: the row offsets of a K-segment (one convolution tap) stay in registers for the
   // whole segment and the next segment's are fetched one K-tile ahead, so the dependent
   // table-load -> DMA-address chain never sits on the critical path.
-  int cur_off[4] = {0, 0, 0, 0}, nxt_off[4] = {0, 0, 0, 0};
+  int cur_off[PA], nxt_off[PA];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) cur_off[j] = nxt_off[j] = 0;
   if (rowoff) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) cur_off[j] = rowoff[a_row[j]];
+    for (int j = 0; j < PA; ++j) cur_off[j] = rowoff[a_row[j]];
   }
   auto stage = [&](int kt, int buf) {
-    const unsigned ldsA =
-        __builtin_amdgcn_readfirstlane(lds0 + buf * 2 * TILE_BYTES + wave * 4 * 1024);
-    const unsigned ldsB = ldsA + TILE_BYTES;
+    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
+    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
     const size_t koff = (size_t)kt * ROW_BYTES;
     if (rowoff) {
       const int k0 = kt * BK;
@@ -143,53 +151,56 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
       const int kin = k0 - seg * p.seg_len;
       if (kin == 0 && kt > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cur_off[j] = nxt_off[j];
+        for (int j = 0; j < PA; ++j) cur_off[j] = nxt_off[j];
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < PA; ++j) {
         const char *src = cur_off[j] >= 0 ? Ab + ((size_t)cur_off[j] + kin) * ES + lchunk_off
                                           : (const char *)g_zero_page + lchunk_off;
         glds16(src, ldsA + j * 1024);
       }
       if (kin + BK == p.seg_len && k0 + BK < p.Kd) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) nxt_off[j] = rowoff[(size_t)(seg + 1) * p.M + a_row[j]];
+        for (int j = 0; j < PA; ++j) nxt_off[j] = rowoff[(size_t)(seg + 1) * p.M + a_row[j]];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) glds16(a_src[j] + koff, ldsA + j * 1024);
+      for (int j = 0; j < PA; ++j) glds16(a_src[j] + koff, ldsA + j * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PB; ++j)
       glds16(w_row[j] < p.N ? w_src[j] + koff : w_src[j], ldsB + j * 1024);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read addresses: row = tile row (lane & 15), logical chunk = 4*s + (lane >> 4)
   const int frow = lane & 15, fq = lane >> 4;
   auto compute = [&](int buf) {
-    const char *ldsA = smem + buf * 2 * TILE_BYTES;
-    const char *ldsB = ldsA + TILE_BYTES;
+    const char *ldsA = smem + buf * STAGE_BYTES;
+    const char *ldsB = ldsA + A_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      uint4 af[4], bf[4];
+      uint4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = wm * 64 + i * 16 + frow;
+      for (int i = 0; i < TM; ++i) {
+        const int ra = wm * (BM / 2) + i * 16 + frow;
         af[i] = *reinterpret_cast<const uint4 *>(ldsA + ra * ROW_BYTES + (((4 * s + fq) ^ (ra & 7)) << 4));
-        const int rb = wn * 64 + i * 16 + frow;
-        bf[i] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * s + fq) ^ (rb & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int rb = wn * (BN / 2) + j * 16 + frow;
+        bf[j] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * s + fq) ^ (rb & 7)) << 4));
       }
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
       } else {
@@ -198,9 +209,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                   __uint_as_float(reinterpret_cast<const unsigned *>(&bf[j])[e]),
                   __uint_as_float(reinterpret_cast<const unsigned *>(&af[i])[e]), acc[i][j], 0, 0, 0);
@@ -232,14 +243,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   const float *Rb = p.residual ? p.residual + (size_t)z * p.strideC : nullptr;
   const bool vec_ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && !(epi & PP_EPI_HEATMAP);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + frow;
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + frow;
     if (m >= p.M) continue;
     const int r = rowmap ? rowmap[m] : m;
     const float *rb = (epi & PP_EPI_ROWBIAS) ? p.rowbias + (size_t)(m % p.rowbias_period) * p.ldc : nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fq * 4;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (vec_ok) {
@@ -343,29 +354,37 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.strideBias = a->strideBias; p.strideRowoff = a->strideRowoff; p.strideRowmap = a->strideRowmap;
   p.epilogue = a->epilogue;
   p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
-  p.tiles_m = cdiv(a->M, BM);
-  p.tiles_n = cdiv(a->N, BN);
   const int batch = a->batch > 0 ? a->batch : 1;
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
+  // tile shape: fewest rounds of the 512 co-resident workgroups (256 CUs x 2), weighted by tile area
+  auto cost = [&](int bm, int bn) {
+    const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
+    return ((tiles + 511) / 512) * (long long)bm * bn;
+  };
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 2, "pp_gemm: bad tile selector %d", a->tile);
+  const bool wide = a->tile == 2 || (a->tile == 0 && cost(192, 96) < cost(128, 128));
+  const int bm = wide ? 192 : 128, bn = wide ? 96 : 128;
+  p.tiles_m = cdiv(a->M, bm);
+  p.tiles_n = cdiv(a->N, bn);
   dim3 grid(p.tiles_m * p.tiles_n, batch);
   hipStream_t s = (hipStream_t)stream;
+  const int lds = gemm_lds_bytes(bm, bn);
+#define PP_LAUNCH_GEMM(T, BM_, BN_)                                                                   \
+  do {                                                                                                \
+    static thread_local bool attr = false;                                                            \
+    if (!attr) {                                                                                      \
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_>),      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));             \
+      attr = true;                                                                                    \
+    }                                                                                                 \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_>), grid, dim3(GEMM_THREADS), lds, s, p);              \
+  } while (0)
   if (a->dtype == PP_BF16) {
-    static thread_local bool attr = false;
-    if (!attr) {
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<bf16_t>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-      attr = true;
-    }
-    hipLaunchKernelGGL(gemm_kernel<bf16_t>, grid, dim3(GEMM_THREADS), GEMM_LDS, s, p);
+    if (wide) PP_LAUNCH_GEMM(bf16_t, 192, 96); else PP_LAUNCH_GEMM(bf16_t, 128, 128);
   } else {
-    static thread_local bool attr = false;
-    if (!attr) {
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<float>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-      attr = true;
-    }
-    hipLaunchKernelGGL(gemm_kernel<float>, grid, dim3(GEMM_THREADS), GEMM_LDS, s, p);
+    if (wide) PP_LAUNCH_GEMM(float, 192, 96); else PP_LAUNCH_GEMM(float, 128, 128);
   }
+#undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");
   return 0;
 }

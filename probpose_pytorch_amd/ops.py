@@ -50,7 +50,7 @@ def _p(t):
 
 def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
-         strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None):
+         strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0):
     """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h."""
     a = _lib.GemmArgs()
     a.A, a.W, a.C = _p(A), _p(W), _p(out)
@@ -71,12 +71,13 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         epilogue |= EPI_HEATMAP
         a.hm_K, a.hm_HW, a.hm_temperature = heatmap
     a.epilogue = epilogue
+    a.tile = tile
     rc = _timed("gemm", 2.0 * M * N * Kd * batch, lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()))
     _lib.check(rc, "pp_gemm")
     return out
 
 
-def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=None):
+def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=None, tile=0):
     """x [M,K] @ w[N,K]^T (+bias, activation / fp32 residual add)."""
     M, Kd = x.shape
     N = w.shape[0]
@@ -86,7 +87,7 @@ def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=No
         dt = torch.float32 if (epilogue & EPI_OUT_F32) else w.dtype
         out = torch.empty((M, N), dtype=dt, device=x.device)
     return gemm(x, w, out, M=M, N=N, Kd=Kd, lda=x.stride(0), ldw=w.stride(0), ldc=out.stride(0),
-                bias=bias, residual=residual, epilogue=epilogue)
+                bias=bias, residual=residual, epilogue=epilogue, tile=tile)
 
 
 def layernorm(x, gamma, beta, eps, out):

@@ -36,12 +36,13 @@ def _tol(dtype, out_dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 768, 768), (300, 200, 128), (1, 17, 256), (257, 129, 64),
-                                   (384, 2304, 768)])
-def test_gemm_plain_bias_tails(ops, dtype, M, N, K):
+                                   (384, 2304, 768), (192, 96, 64), (193, 97, 128)])
+def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
     A, W = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, K ** -0.5)
     b = _rand((N,), torch.float32, 3)
-    out = ops.linear(A, W, b)
+    out = ops.linear(A, W, b, tile=tile)
     ref = A.double() @ W.double().t() + b.double()
     torch.testing.assert_close(out.double(), ref, **_tol(dtype, dtype))
 
@@ -77,8 +78,13 @@ def test_gemm_exact_integer_data_catches_layout_bugs(ops, dtype):
     g = torch.Generator().manual_seed(0)
     A = torch.randint(-3, 4, (M, K), generator=g).to(dtype).cuda()
     W = torch.randint(-3, 4, (N, K), generator=g).to(dtype).cuda()
-    out = ops.linear(A, W, out_dtype=torch.float32)
-    assert torch.equal(out.double(), A.double() @ W.double().t())
+    for tile in (0, 1, 2):
+        out = ops.linear(A, W, out_dtype=torch.float32, tile=tile)
+        assert torch.equal(out.double(), A.double() @ W.double().t())
+    # auto-selection picks the 192x96 tile when it saves a round of workgroups (M = 16 crops x 192)
+    A2 = torch.randint(-3, 4, (3072, K), generator=g).to(dtype).cuda()
+    W2 = torch.randint(-3, 4, (3072, K), generator=g).to(dtype).cuda()
+    assert torch.equal(ops.linear(A2, W2, out_dtype=torch.float32).double(), A2.double() @ W2.double().t())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -92,8 +98,14 @@ def test_gemm_conv3x3_gather_batched_branches(ops, dtype):
     Wp = torch.stack([pack.conv_taps_major(wt[i].cpu()) for i in range(4)]).to(dtype).cuda()
     ro = pack.conv_gather_table(B, h, w, 3, 3, 1, 1, 4 * C).cuda()
     out = torch.empty((B * h * w, 4 * C), dtype=dtype, device="cuda")
-    ops.gemm(x, Wp, out, M=B * h * w, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C, bias=bias, rowoff=ro,
-             seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C, strideBias=C)
+    for tile in (1, 2):
+        out.zero_()
+        ops.gemm(x, Wp, out, M=B * h * w, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C, bias=bias, rowoff=ro,
+                 seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C, strideBias=C, tile=tile)
+        _check_branches(x, Wp, bias, out, B, h, w, C, dtype)
+
+
+def _check_branches(x, Wp, bias, out, B, h, w, C, dtype):
     for i in range(4):
         xi = x[:, i * C:(i + 1) * C].double().reshape(B, h, w, C).permute(0, 3, 1, 2)
         wi = Wp[i].double().reshape(C, 3, 3, C).permute(0, 3, 1, 2)
@@ -102,8 +114,9 @@ def test_gemm_conv3x3_gather_batched_branches(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2])
 @pytest.mark.parametrize("k", [4, 3, 2])
-def test_gemm_deconv_parities_scatter(ops, dtype, k):
+def test_gemm_deconv_parities_scatter(ops, dtype, k, tile):
     from probpose_pytorch_amd import pack
     B, h, w, Cin, Cout = 2, 8, 6, 64, 128
     x = _rand((B * h * w, Cin), dtype, 1)
@@ -115,7 +128,7 @@ def test_gemm_deconv_parities_scatter(ops, dtype, k):
     out = torch.full((4 * M, Cout), float("nan"), dtype=dtype, device="cuda")
     ops.gemm(x, Wp, out, M=M, N=Cout, Kd=4 * Cin, lda=Cin, ldw=4 * Cin, ldc=Cout, bias=bias, rowoff=ro.cuda(),
              seg_len=Cin, out_rowmap=rm.cuda(), batch=4, strideW=Cout * 4 * Cin, strideRowoff=4 * M,
-             strideRowmap=M, epilogue=ops.EPI_RELU)
+             strideRowmap=M, epilogue=ops.EPI_RELU, tile=tile)
     pad, op = pack.deconv_geometry(k)
     # reference from the same (rounded) packed weights: rebuild the deconv weight from Wp
     xi = x.double().reshape(B, h, w, Cin).permute(0, 3, 1, 2)
