@@ -57,6 +57,26 @@ def flops_per_crop(cfg) -> float:
     return float(patch + blocks + deconv + final + aux)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the GEMM / decode kernels from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None, None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"]
+    n = b = 0
+    dec = None
+    for name, v in k.items():
+        if "gemm_kernel" in name:
+            n += v["launches"]
+            b += v["launches"] * v["hbm_bytes_per_launch"]
+        if "decode_lds_kernel" in name:
+            dec = v["hbm_bytes_per_launch"]
+    return (b / n if n else None), dec, os.path.basename(files[-1])
+
+
 def sigmas_for(K: int) -> np.ndarray:
     from probpose_pytorch_amd.synthetic import torch as _t  # noqa: F401
     if K == 17:
@@ -235,6 +255,7 @@ def main():
         achieved = g_flops / g_t / 1e12
         d_n, d_bytes, d_t = per_step.get("decode", (0, 0.0, 1.0))
         a_n, a_flops, a_t = per_step.get("attention", (0, 0.0, 1.0))
+        g_traffic, d_traffic, traffic_src = pmc_traffic() if args.config == "vit_b" and B == 64 else (None, None, None)
         line = {
             "metric": "person_crops_per_sec", "value": round(crops_per_s, 2), "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -247,12 +268,12 @@ def main():
             "decode_ms": round(d_t * 1e3, 4),
             "model_tflops": round(flops_per_crop(cfg) * crops_per_s / world / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel", "achieved": round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
-                         "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": g_traffic,
+                         "traffic_source": traffic_src, "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
                          "flop_per_launch": round(g_flops / max(g_n, 1), 0)},
             "roofline_decode": {"bound": "hbm", "kernel": "pp::decode_lds_kernel",
                                 "achieved": round(d_bytes / d_t / 1e9, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                "frac": round(d_bytes / d_t / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                                "frac": round(d_bytes / d_t / 1e9 / PEAK_HBM_GBPS, 4), "traffic": d_traffic,
                                 "bytes_per_launch": d_bytes},
             "attention": {"achieved_tflops": round(a_flops / a_t / 1e12, 2), "ms_per_step": round(a_t * 1e3, 3)},
             "kernel_ms_per_step": {k: round(v[2] * 1e3, 3) for k, v in per_step.items()},

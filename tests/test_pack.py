@@ -85,3 +85,16 @@ def test_modules_refuse_cpu_tensors():
     bb = ScratchViTBackbone((64, 48), 16, embed_dim=128, depth=1, num_heads=2)
     with pytest.raises(_lib.HipExtensionError):
         bb(torch.zeros(1, 3, 64, 48))
+
+
+def test_drop_in_import_paths():
+    """`import probpose.<module>` (the reference's package name) resolves to the HIP-backed modules."""
+    import probpose.codec
+    import probpose_pytorch_amd.codec
+    from probpose.backbone import ScratchViTBackbone  # noqa: F401
+    from probpose.codec import Codec, ProbMap  # noqa: F401
+    from probpose.head import ProbMapHead  # noqa: F401
+    from probpose.heatmap import get_heatmap_expected_value  # noqa: F401
+    from probpose.model import ProbPoseModel  # noqa: F401
+    from probpose.util import to_numpy  # noqa: F401
+    assert probpose.codec is probpose_pytorch_amd.codec
