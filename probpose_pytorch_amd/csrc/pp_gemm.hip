@@ -16,6 +16,9 @@
 // LDS image stays lane-linear for the DMA while ds_read_b128 fragment reads
 // are bank-conflict free.  bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode):
 // v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain.
+#include <type_traits>
+#include <utility>
+
 #include "pp_common.h"
 
 namespace pp {
@@ -24,8 +27,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROW_BYTES = 128;                 // bytes of K per staged row
-constexpr int GEMM_THREADS = 256;
-constexpr int gemm_lds_bytes(int BM, int BN) { return 2 * (BM + BN) * ROW_BYTES; }  // double buffer
+constexpr int gemm_lds_bytes(int BM, int BN, int stages) { return stages * (BM + BN) * ROW_BYTES; }
+
+// Diagnostic build only (-DPP_GEMM_STAMPS, never shipped): per-wave cycle shares of the K-loop
+// phases are written to the buffer passed in GemmParams::rowbias when epilogue bit 30 is set.
+#ifdef PP_GEMM_STAMPS
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define PP_STAMP(var) const unsigned long long var = stamp()
+#define PP_ACC(dst, a, b) dst += (b) - (a)
+#else
+#define PP_STAMP(var)
+#define PP_ACC(dst, a, b)
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -81,24 +105,35 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return 0.5f * x * (1.0f + copysignf(erfz, x));
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
+// WGM x WGN waves per workgroup; STAGES LDS buffers (prefetch distance STAGES-1, counted vmcnt).
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = ROW_BYTES / ES;  // elements of K per tile
-  constexpr int PA = BM / 32, PB = BN / 32;      // 1-KiB DMA pieces (8 rows) per wave per K-tile
-  constexpr int TM = BM / 32, TN = BN / 32;      // 16x16 MFMA tiles per wave: (BM/2)/16 x (BN/2)/16
+  constexpr int NW = WGM * WGN;
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces (8 rows) per wave per K-tile
+  constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;  // 16x16 MFMA tiles per wave
   constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0, "tile");
 
-  // ---- tile assignment: XCD-aware remap (blocks b, b+8 share an XCD/L2) so
-  // the tiles sharing one A row-panel run on one XCD back to back.
-  const int ntiles = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  // ---- tile assignment, XCD-aware (speed only, never correctness): workgroups b and b+8 share an
+  // XCD and its 4 MiB L2.  The tile grid is cut into blocks of 8 x RN tiles (one block = one round
+  // of an XCD's 32 CUs); block g goes to XCD g % 8 and blocks are numbered N-fastest, so an XCD
+  // keeps working on the same few W column-slices (L2-resident) while A row-panels stream through,
+  // each panel shared by the RN tiles of the block.  Out-of-range slots of partial blocks exit.
+  constexpr int RM = 8, RN = (NW == 8) ? 4 : 8, RT = RM * RN;
+  const int nbm = (p.tiles_m + RM - 1) / RM, nbn = (p.tiles_n + RN - 1) / RN;
+  int tm, tn;
   {
-    const int q = ntiles >> 3, r = ntiles & 7, x = bid & 7, j = bid >> 3;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int g = (j / RT) * 8 + x, idx = j % RT;
+    if (g >= nbm * nbn) return;
+    const int bmi = g / nbn, bni = g - bmi * nbn;
+    tm = bmi * RM + idx / RN;
+    tn = bni * RN + idx % RN;
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
   }
-  const int tm = bid / p.tiles_n, tn = bid - tm * p.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
   const char *Ab = p.A + (size_t)z * p.strideA * ES;
@@ -106,7 +141,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
   const int32_t *rowoff = p.rowoff ? p.rowoff + (size_t)z * p.strideRowoff : nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
 
   // ---- staging geometry: each wave issues PA A-pieces + PB W-pieces (8 rows x 128 B) per K-tile.
   // lane -> (row in piece, physical 16-B chunk); logical chunk = physical ^ (row & 7).
@@ -141,140 +176,246 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int j = 0; j < PA; ++j) cur_off[j] = rowoff[a_row[j]];
   }
-  auto stage = [&](int kt, int buf) {
-    const unsigned ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
-    const unsigned ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
-    const size_t koff = (size_t)kt * ROW_BYTES;
+  // One K-tile's DMA is split into its PA + PB pieces so the pieces can be issued BETWEEN MFMA
+  // groups: a global_load_lds blocks the issuing wave for ~100-200 cycles while the CU's address
+  // unit drains its queue (measured); issued back to back right after the barrier, all waves stall
+  // there together and the matrix pipe idles for ~45 % of the K-loop.
+  int st_kin = 0;
+  unsigned st_ldsA = 0, st_ldsB = 0;
+  size_t st_koff = 0;
+  auto stage_begin = [&](int kt, int buf) {
+    st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
+    st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
+    st_koff = (size_t)kt * ROW_BYTES;
     if (rowoff) {
       const int k0 = kt * BK;
       const int seg = k0 / p.seg_len;
-      const int kin = k0 - seg * p.seg_len;
-      if (kin == 0 && kt > 0) {
+      st_kin = k0 - seg * p.seg_len;
+      if (st_kin == 0 && kt > 0) {
 #pragma unroll
         for (int j = 0; j < PA; ++j) cur_off[j] = nxt_off[j];
       }
-#pragma unroll
-      for (int j = 0; j < PA; ++j) {
-        const char *src = cur_off[j] >= 0 ? Ab + ((size_t)cur_off[j] + kin) * ES + lchunk_off
-                                          : (const char *)g_zero_page + lchunk_off;
-        glds16(src, ldsA + j * 1024);
-      }
-      if (kin + BK == p.seg_len && k0 + BK < p.Kd) {
+    }
+  };
+  auto stage_piece = [&](auto qc) {   // qc: compile-time piece index 0 .. PA+PB-1
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < PA) {
+      const char *src;
+      if (rowoff)
+        src = cur_off[q] >= 0 ? Ab + ((size_t)cur_off[q] + st_kin) * ES + lchunk_off
+                              : (const char *)g_zero_page + lchunk_off;
+      else
+        src = a_src[q] + st_koff;
+      glds16(src, st_ldsA + q * 1024);
+    } else {
+      constexpr int j = q - PA;
+      glds16(w_row[j] < p.N ? w_src[j] + st_koff : w_src[j], st_ldsB + j * 1024);
+    }
+  };
+  auto stage_end = [&](int kt) {
+    if (rowoff) {
+      const int k0 = kt * BK;
+      const int seg = k0 / p.seg_len;
+      if (st_kin + BK == p.seg_len && k0 + BK < p.Kd) {
 #pragma unroll
         for (int j = 0; j < PA; ++j) nxt_off[j] = rowoff[(size_t)(seg + 1) * p.M + a_row[j]];
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < PA; ++j) glds16(a_src[j] + koff, ldsA + j * 1024);
     }
-#pragma unroll
-    for (int j = 0; j < PB; ++j)
-      glds16(w_row[j] < p.N ? w_src[j] + koff : w_src[j], ldsB + j * 1024);
+  };
+  auto stage_all = [&](int kt, int buf) {
+    stage_begin(kt, buf);
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      (stage_piece(std::integral_constant<int, Q>{}), ...);
+    }(std::make_integer_sequence<int, PA + PB>{});
+    stage_end(kt);
   };
 
   f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read addresses: row = tile row (lane & 15), logical chunk = 4*s + (lane >> 4)
   const int frow = lane & 15, fq = lane >> 4;
-  auto compute = [&](int buf) {
+  constexpr int PIECES = PA + PB;
+  constexpr int GROUPS = 2 * TM;  // MFMA groups per K-tile (one A row-tile x TN column tiles each)
+
+  // compute K-tile `buf`; when DO_STAGE, interleave the DMA pieces of the tile being prefetched
+  auto compute = [&](int buf, auto do_stage_c) {
+    constexpr bool DO_STAGE = decltype(do_stage_c)::value;
     const char *ldsA = smem + buf * STAGE_BYTES;
     const char *ldsB = ldsA + A_BYTES;
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ([&] {
+        constexpr int s = S;
+        uint4 af[TM], bf[TN];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) {
+          const int ra = wm * (BM / WGM) + i * 16 + frow;
+          af[i] = *reinterpret_cast<const uint4 *>(ldsA + ra * ROW_BYTES + (((4 * s + fq) ^ (ra & 7)) << 4));
+        }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ra = wm * (BM / 2) + i * 16 + frow;
-        af[i] = *reinterpret_cast<const uint4 *>(ldsA + ra * ROW_BYTES + (((4 * s + fq) ^ (ra & 7)) << 4));
-      }
+        for (int j = 0; j < TN; ++j) {
+          const int rb = wn * (BN / WGN) + j * 16 + frow;
+          bf[j] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * s + fq) ^ (rb & 7)) << 4));
+        }
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+          ([&] {
+            constexpr int i = I;
+            constexpr int grp = s * TM + i;
+            if constexpr (DO_STAGE) {
+              // pieces whose slot floor(q * GROUPS / PIECES) equals this group
+              [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                ([&] {
+                  if constexpr ((Q * GROUPS) / PIECES == grp) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage_piece(std::integral_constant<int, Q>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
+                }(), ...);
+              }(std::make_integer_sequence<int, PIECES>{});
+            }
+            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int rb = wn * (BN / 2) + j * 16 + frow;
-        bf[j] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * s + fq) ^ (rb & 7)) << 4));
-      }
-      if constexpr (sizeof(T) == 2) {
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
+            } else {
+              // fp32: the chunk holds 4 consecutive k; MFMA step e takes element e of every lane's
+              // chunk (k slots 16s + 4*fq + e, the same permutation on both operands).
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+              for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
-      } else {
-        // fp32: the chunk holds 4 consecutive k; MFMA step e takes element e of every lane's
-        // chunk (k slots 16s + 4*fq + e, the same permutation on both operands).
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                  __uint_as_float(reinterpret_cast<const unsigned *>(&bf[j])[e]),
-                  __uint_as_float(reinterpret_cast<const unsigned *>(&af[i])[e]), acc[i][j], 0, 0, 0);
-      }
-    }
+                for (int j = 0; j < TN; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                      __uint_as_float(reinterpret_cast<const unsigned *>(&bf[j])[e]),
+                      __uint_as_float(reinterpret_cast<const unsigned *>(&af[i])[e]), acc[i][j], 0, 0, 0);
+            }
+          }(), ...);
+        }(std::make_integer_sequence<int, TM>{});
+      }(), ...);
+    }(std::make_integer_sequence<int, 2>{});
   };
 
-  // ---- main loop: DMA of tile t+1 in flight while tile t feeds the MFMAs
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nkt - 1; ++kt) {
-    stage(kt + 1, cur ^ 1);
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
+  // ---- every additive epilogue term (bias, pos-embed row bias, the fp32 residual that the proj/fc2
+  // GEMMs update in place) is loaded straight INTO the accumulators before the K-loop: the loads are
+  // older than every DMA piece, their latency hides under the pipeline fill, and the epilogue needs no
+  // global loads at all (the in-place residual aliases C, so hipcc could never hoist those loads).
+  const int epi = p.epilogue;
+  const float *__restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
+  const int32_t *__restrict__ rowmap = p.out_rowmap ? p.out_rowmap + (size_t)z * p.strideRowmap : nullptr;
+  const float *Rb = p.residual ? p.residual + (size_t)z * p.strideC : nullptr;
+  const bool vec_ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && !(epi & PP_EPI_HEATMAP);
+  int out_row[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
+    out_row[i] = (rowmap && m < p.M) ? rowmap[m] : m;
   }
-  compute(cur);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
+      f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < p.M) {
+        if (vec_ok) {
+          if (n < p.N) {
+            if (epi & PP_EPI_BIAS) {
+              const float4 t = *reinterpret_cast<const float4 *>(bias + n);
+              c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += t.w;
+            }
+            if (epi & PP_EPI_ROWBIAS) {
+              const float4 t = *reinterpret_cast<const float4 *>(p.rowbias + (size_t)(m % p.rowbias_period) * p.ldc + n);
+              c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += t.w;
+            }
+            if (epi & PP_EPI_RESIDUAL) {
+              const float4 t = *reinterpret_cast<const float4 *>(Rb + (size_t)out_row[i] * p.ldc + n);
+              c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += t.w;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < p.N) {
+              if (epi & PP_EPI_BIAS) c[e] += bias[n + e];
+              if (epi & PP_EPI_ROWBIAS) c[e] += p.rowbias[(size_t)(m % p.rowbias_period) * p.ldc + n + e];
+              if ((epi & PP_EPI_RESIDUAL) && !(epi & PP_EPI_HEATMAP)) c[e] += Rb[(size_t)out_row[i] * p.ldc + n + e];
+            }
+          }
+        }
+      }
+      acc[i][j] = c;
+    }
+  }
+
+  // ---- main loop.  STAGES-1 K-tiles of DMA stay in flight across the barrier: the wait that
+  // retires tile t is a COUNTED vmcnt (never 0 in steady state), then one raw s_barrier makes every
+  // wave's pieces of tile t visible and proves every wave finished reading the buffer that tile
+  // t+STAGES-1 is about to overwrite (it was consumed in iteration t-1).
+#ifdef PP_GEMM_STAMPS
+  unsigned long long c_wait = 0, c_bar = 0, c_stage = 0, c_comp = 0;
+#endif
+  PP_STAMP(t_begin);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nkt) stage_all(s, s);
+  // the loads above (bias, row map) are older than every DMA piece: retire them once, here, so that
+  // inside the loop only DMA pieces are outstanding and the counted waits are exact
+  PP_STAMP(t_pro);
+  int buf = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    PP_STAMP(ta);
+    if (kt + STAGES - 1 <= nkt) {
+      wait_vmcnt<(STAGES - 2) * PIECES>();        // steady state: STAGES-2 younger tiles may still fly
+    } else {
+      wait_vmcnt<0>();                            // drain at the tail (fewer tiles were issued)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_STAMP(tb);
+    __builtin_amdgcn_s_barrier();
+    PP_STAMP(tc);
+    const int nt = kt + STAGES - 1;
+    if (nt < nkt) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage_begin(nt, nb);
+      compute(buf, std::true_type{});
+      stage_end(nt);
+    } else {
+      compute(buf, std::false_type{});
+    }
+    PP_STAMP(te);
+    PP_ACC(c_bar, tb, tc);
+    PP_ACC(c_wait, ta, tb);
+    PP_ACC(c_comp, tc, te);
+    if (++buf == STAGES) buf = 0;
+  }
+  PP_STAMP(t_loop);
 
   // ---- epilogue.  The W fragment is the MFMA "A" operand and the activation fragment the "B"
   // operand, so a 16x16 accumulator tile holds C^T: lane (frow, fq) owns output row m = .. + frow and
   // the 4 CONSECUTIVE columns n = .. + 4*fq + e -> 8-byte (bf16) / 16-byte (fp32) vector stores.
-  const int epi = p.epilogue;
-  const float *bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
-  const int32_t *rowmap = p.out_rowmap ? p.out_rowmap + (size_t)z * p.strideRowmap : nullptr;
+  // All additive terms are already in the accumulators: activation, convert, store.
   char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
-  const float *Rb = p.residual ? p.residual + (size_t)z * p.strideC : nullptr;
-  const bool vec_ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && !(epi & PP_EPI_HEATMAP);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 16 + frow;
+    const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
     if (m >= p.M) continue;
-    const int r = rowmap ? rowmap[m] : m;
-    const float *rb = (epi & PP_EPI_ROWBIAS) ? p.rowbias + (size_t)(m % p.rowbias_period) * p.ldc : nullptr;
+    const int r = out_row[i];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+      const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (epi & PP_EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
+      }
+      if (epi & PP_EPI_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
       if (vec_ok) {
-        if (epi & PP_EPI_BIAS) {
-          const float4 b4 = *reinterpret_cast<const float4 *>(bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-        if (rb) {
-          const float4 b4 = *reinterpret_cast<const float4 *>(rb + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-        if (epi & PP_EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
-        }
-        if (epi & PP_EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
         const size_t idx = (size_t)r * p.ldc + n;
-        if (epi & PP_EPI_RESIDUAL) {
-          const float4 r4 = *reinterpret_cast<const float4 *>(Rb + idx);
-          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-        }
         if ((epi & PP_EPI_OUT_F32) || sizeof(T) == 4) {
           *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Cb) + idx) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -291,10 +432,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
         const int ne = n + e;
         if (ne >= p.N) continue;
         float x = v[e];
-        if (epi & PP_EPI_BIAS) x += bias[ne];
-        if (rb) x += rb[ne];
-        if (epi & PP_EPI_GELU) x = (sizeof(T) == 2) ? gelu_fast(x) : gelu_erf(x);
-        if (epi & PP_EPI_RELU) x = fmaxf(x, 0.f);
         if (epi & PP_EPI_HEATMAP) {
           x = fminf(fmaxf(x / p.hm_temperature, 0.f), 1.f);
           const int b = r / p.hm_HW, hw = r - b * p.hm_HW;
@@ -302,7 +439,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
           continue;
         }
         const size_t idx = (size_t)r * p.ldc + ne;
-        if (epi & PP_EPI_RESIDUAL) x += Rb[idx];
         if (epi & PP_EPI_OUT_F32)
           reinterpret_cast<float *>(Cb)[idx] = x;
         else
@@ -310,9 +446,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(GemmParams p) {
       }
     }
   }
+#ifdef PP_GEMM_STAMPS
+  if ((p.epilogue & (1 << 30)) && lane == 0) {
+    PP_STAMP(t_end);
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
+                            ((size_t)blockIdx.x * NW + wave) * 8;
+    o[0] = t_pro - t_begin; o[1] = c_wait; o[2] = c_bar; o[3] = c_stage; o[4] = c_comp;  // stage now inside compute
+    o[5] = t_end - t_loop; o[6] = t_end - t_begin; o[7] = t_begin;
+  }
+#endif
 }
 
 }  // namespace pp
+
+#ifndef PP_CFG3_SPEEDUP
+#define PP_CFG3_SPEEDUP 1.3  // measured: one 8-wave 3-stage 192x192 tile per CU vs two co-resident 4-wave tiles
+#endif
 
 extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   using namespace pp;
@@ -356,33 +505,52 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
   const int batch = a->batch > 0 ? a->batch : 1;
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
-  // tile shape: fewest rounds of the 512 co-resident workgroups (256 CUs x 2), weighted by tile area
-  auto cost = [&](int bm, int bn) {
+  // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
+  // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU).  Auto: cost = rounds of co-resident
+  // workgroups x tile area / relative per-CU throughput of the configuration.
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 3, "pp_gemm: bad tile selector %d", a->tile);
+  auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
-    return ((tiles + 511) / 512) * (long long)bm * bn;
+    return (tiles + slots - 1) / slots;
   };
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 2, "pp_gemm: bad tile selector %d", a->tile);
-  const bool wide = a->tile == 2 || (a->tile == 0 && cost(192, 96) < cost(128, 128));
-  const int bm = wide ? 192 : 128, bn = wide ? 96 : 128;
+  int cfg = a->tile;
+  if (cfg == 0) {
+    const double c1 = (double)rounds(128, 128, 512) * 128 * 128 * 2;   // 2 workgroups share a CU
+    const double c2 = (double)rounds(192, 96, 512) * 192 * 96 * 2;
+    const double c3 = (double)rounds(192, 192, 256) * 192 * 192 / PP_CFG3_SPEEDUP;
+    cfg = 1;
+    double best = c1;
+    if (c2 < best) { best = c2; cfg = 2; }
+    if (c3 < best) { best = c3; cfg = 3; }
+  }
+  const int bm = cfg == 1 ? 128 : 192, bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : 192);
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
-  dim3 grid(p.tiles_m * p.tiles_n, batch);
+  const int rn_ = cfg == 3 ? 4 : 8;
+  const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
+  dim3 grid((unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_), batch);
   hipStream_t s = (hipStream_t)stream;
-  const int lds = gemm_lds_bytes(bm, bn);
-#define PP_LAUNCH_GEMM(T, BM_, BN_)                                                                   \
+#define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
   do {                                                                                                \
+    constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
     static thread_local bool attr = false;                                                            \
     if (!attr) {                                                                                      \
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_>),      \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));             \
+      PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
+          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_>),                  \
+          hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
       attr = true;                                                                                    \
     }                                                                                                 \
-    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_>), grid, dim3(GEMM_THREADS), lds, s, p);              \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_>), grid, dim3(64 * WGM_ * WGN_), lds, \
+                       s, p);                                                                         \
   } while (0)
   if (a->dtype == PP_BF16) {
-    if (wide) PP_LAUNCH_GEMM(bf16_t, 192, 96); else PP_LAUNCH_GEMM(bf16_t, 128, 128);
+    if (cfg == 1) PP_LAUNCH_GEMM(bf16_t, 128, 128, 2, 2, 2);
+    else if (cfg == 2) PP_LAUNCH_GEMM(bf16_t, 192, 96, 2, 2, 2);
+    else PP_LAUNCH_GEMM(bf16_t, 192, 192, 2, 4, 3);
   } else {
-    if (wide) PP_LAUNCH_GEMM(float, 192, 96); else PP_LAUNCH_GEMM(float, 128, 128);
+    if (cfg == 1) PP_LAUNCH_GEMM(float, 128, 128, 2, 2, 2);
+    else if (cfg == 2) PP_LAUNCH_GEMM(float, 192, 96, 2, 2, 2);
+    else PP_LAUNCH_GEMM(float, 192, 192, 2, 4, 3);
   }
 #undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");
