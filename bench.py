@@ -240,7 +240,7 @@ def main():
         torch.cuda.synchronize()
         ops.set_profile(None)
     agg = {}
-    for name, work, s, e in prof:
+    for name, work, s, e, _info in prof:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += work

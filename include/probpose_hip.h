@@ -111,7 +111,7 @@ typedef struct pp_gemm_args {
   int hm_K, hm_HW;              /* PP_EPI_HEATMAP geometry              */
   float hm_temperature;         /* head.py:107 (0.5)                    */
   int tile;                     /* 0 = auto (fewest rounds of resident workgroups), 1 = 128x128,
-                                   2 = 192x96 (4 waves, 2 LDS stages), 3 = 192x192 (8 waves, 3 stages) */
+                                   2 = 192x96 (4 waves, 2 LDS stages), 3 = 192x192, 4 = 192x128 (8 waves, 3 stages) */
 } pp_gemm_args;
 int pp_gemm(const pp_gemm_args *args, void *stream);
 
@@ -135,6 +135,13 @@ int pp_patchify(const float *x, void *out, int B, int H, int W, int patch, int d
  * x [B, h, w, C] -> out [B, h/kh, w/kw, C]. */
 int pp_maxpool_relu(const void *x, void *out, int B, int h, int w, int C, int kh, int kw,
                     int dtype, void *stream);
+
+/* Final 1x1 conv + /temperature + clamp(0,1), channels-last rows -> NCHW float32 (head.py:525-532),
+ * as a streaming (HBM-bound) kernel for small K:  x [B*HW, Cin], w [K, Cin], bias [K] ->
+ * heat [B, K, HW] f32 = clamp((x w^T + bias) / temperature, 0, 1).  (K*Cin*sizeof + 64 rows must fit
+ * LDS; larger final layers / k > 1 kernels go through pp_gemm with PP_EPI_HEATMAP.) */
+int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B, int HW,
+                     int Cin, int K, float temperature, int dtype, void *stream);
 
 /* Aux tail: 1x1 conv C->K on pooled 1x1 features + Sigmoid/ReLU (head.py:277-286,:391-400).
  * x [4 branches][B, C] -> out [4][B,K] f32 (branches 0..2 sigmoid, 3 relu). */

@@ -48,6 +48,7 @@ _SIGNATURES = {
     "pp_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pp_final_heatmap": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "pp_aux_tail": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_tokens_to_nchw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_nchw_to_tokens": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -51,7 +51,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+// Zero rows (W rows beyond N, zero-padding taps of the implicit convolutions) are DMA'd from a 64 KiB
+// zero region, each lane/workgroup at a different 128-B line: one shared line would funnel every
+// such request of the chip through a single L2 channel (measured: the K=17 heatmap layer, whose W
+// tile is 82 % zero rows, ran 6x slower from a 256-B zero page).
+constexpr int ZERO_REGION = 64 * 1024;
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[ZERO_REGION];
 
 struct GemmParams {
   const char *A;
@@ -70,6 +75,7 @@ struct GemmParams {
   int hm_K, hm_HW;
   float hm_temperature;
   int tiles_m, tiles_n;
+  int blocked;  // XCD-blocked tile order (large grids) vs plain order
 };
 
 // LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte offset (M0) + lane * 16.  Issued
@@ -123,9 +129,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // keeps working on the same few W column-slices (L2-resident) while A row-panels stream through,
   // each panel shared by the RN tiles of the block.  Out-of-range slots of partial blocks exit.
   constexpr int RM = 8, RN = (NW == 8) ? 4 : 8, RT = RM * RN;
-  const int nbm = (p.tiles_m + RM - 1) / RM, nbn = (p.tiles_n + RN - 1) / RN;
   int tm, tn;
-  {
+  if (p.blocked) {
+    const int nbm = (p.tiles_m + RM - 1) / RM, nbn = (p.tiles_n + RN - 1) / RN;
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int g = (j / RT) * 8 + x, idx = j % RT;
     if (g >= nbm * nbn) return;
@@ -133,6 +139,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     tm = bmi * RM + idx / RN;
     tn = bni * RN + idx % RN;
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+  } else {  // few tiles: one workgroup per tile in launch order, spread over all XCDs
+    tm = blockIdx.x / p.tiles_n;
+    tn = blockIdx.x - tm * p.tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
@@ -146,6 +155,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // ---- staging geometry: each wave issues PA A-pieces + PB W-pieces (8 rows x 128 B) per K-tile.
   // lane -> (row in piece, physical 16-B chunk); logical chunk = physical ^ (row & 7).
   const int prow = lane >> 3, pchunk = lane & 7;
+  // this lane's line inside the zero region: spread over workgroups, waves and piece rows
+  const char *zero_line = (const char *)g_zero_page +
+                          ((((blockIdx.x * 29 + blockIdx.y * 7 + wave) * 8 + prow) & 7) * 128 + pchunk * 16) +
+                          (((blockIdx.x * 13 + wave * 5) & 7) * 8192);
   int a_row[PA], w_row[PB];
   const char *a_src[PA];
   const char *w_src[PB];
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     const int r = (wave * PB + j) * 8 + prow;
     w_row[j] = n0 + r;
     w_src[j] = (w_row[j] < p.N) ? Wb + (size_t)w_row[j] * p.ldw * ES + (pchunk ^ prow) * 16
-                                : (const char *)g_zero_page + (pchunk ^ prow) * 16;
+                                : zero_line + ((j * 5 + 3) & 7) * 1024;
   }
   const int lchunk_off = (pchunk ^ prow) * 16;  // (row & 7) == prow for every piece
   const int nkt = p.Kd / BK;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
       const char *src;
       if (rowoff)
         src = cur_off[q] >= 0 ? Ab + ((size_t)cur_off[q] + st_kin) * ES + lchunk_off
-                              : (const char *)g_zero_page + lchunk_off;
+                              : zero_line + (q & 7) * 1024;
       else
         src = a_src[q] + st_koff;
       glds16(src, st_ldsA + q * 1024);
@@ -506,9 +519,10 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   const int batch = a->batch > 0 ? a->batch : 1;
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
-  // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU).  Auto: cost = rounds of co-resident
-  // workgroups x tile area / relative per-CU throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 3, "pp_gemm: bad tile selector %d", a->tile);
+  // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages; N = 256
+  // layers).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
+  // throughput of the configuration.
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 4, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -518,17 +532,20 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     const double c1 = (double)rounds(128, 128, 512) * 128 * 128 * 2;   // 2 workgroups share a CU
     const double c2 = (double)rounds(192, 96, 512) * 192 * 96 * 2;
     const double c3 = (double)rounds(192, 192, 256) * 192 * 192 / PP_CFG3_SPEEDUP;
+    const double c4 = (double)rounds(192, 128, 256) * 192 * 128 / (PP_CFG3_SPEEDUP * 0.9);
     cfg = 1;
     double best = c1;
     if (c2 < best) { best = c2; cfg = 2; }
-    if (c3 < best) { best = c3; cfg = 3; }
+    if (c4 < best) { best = c4; cfg = 4; }
+    if (c3 <= best) { best = c3; cfg = 3; }
   }
-  const int bm = cfg == 1 ? 128 : 192, bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : 192);
+  const int bm = cfg == 1 ? 128 : 192, bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : (cfg == 3 ? 192 : 128));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
-  const int rn_ = cfg == 3 ? 4 : 8;
+  const int rn_ = (cfg >= 3) ? 4 : 8;
   const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
-  dim3 grid((unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_), batch);
+  p.blocked = nblk >= 16 ? 1 : 0;
+  dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
 #define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
   do {                                                                                                \
@@ -546,11 +563,13 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   if (a->dtype == PP_BF16) {
     if (cfg == 1) PP_LAUNCH_GEMM(bf16_t, 128, 128, 2, 2, 2);
     else if (cfg == 2) PP_LAUNCH_GEMM(bf16_t, 192, 96, 2, 2, 2);
-    else PP_LAUNCH_GEMM(bf16_t, 192, 192, 2, 4, 3);
+    else if (cfg == 3) PP_LAUNCH_GEMM(bf16_t, 192, 192, 2, 4, 3);
+    else PP_LAUNCH_GEMM(bf16_t, 192, 128, 2, 4, 3);
   } else {
     if (cfg == 1) PP_LAUNCH_GEMM(float, 128, 128, 2, 2, 2);
     else if (cfg == 2) PP_LAUNCH_GEMM(float, 192, 96, 2, 2, 2);
-    else PP_LAUNCH_GEMM(float, 192, 192, 2, 4, 3);
+    else if (cfg == 3) PP_LAUNCH_GEMM(float, 192, 192, 2, 4, 3);
+    else PP_LAUNCH_GEMM(float, 192, 128, 2, 4, 3);
   }
 #undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");

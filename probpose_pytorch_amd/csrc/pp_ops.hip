@@ -162,6 +162,71 @@ __global__ __launch_bounds__(256) void aux_tail_kernel(const T *__restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------
+// Final 1x1 heatmap layer (head.py:525-532): heat[b,k,hw] = clamp((x[b*HW+hw,:] . w[k,:] + bias[k]) / T, 0, 1).
+// K is tiny (17) and the layer reads 100 MB of activations: HBM-bound, so a streaming kernel (64
+// pixel rows per workgroup staged once through LDS, weights broadcast from LDS, NCHW float32 stores
+// that are 256-B contiguous per k) instead of a 128-wide MFMA tile that would be 87 % padding.
+// ---------------------------------------------------------------------------
+constexpr int FH_ROWS = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void final_heatmap_kernel(const T *__restrict__ x, const T *__restrict__ w,
+                                                            const float *__restrict__ bias,
+                                                            float *__restrict__ out, int M, int HW, int Cin,
+                                                            int K, float temperature) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int VEC = 16 / (int)sizeof(T);       // elements per 16-B chunk
+  const int chunks = Cin / VEC;                  // per row
+  const int xstride = (chunks + 1) * 16;         // +1 chunk pad: 64 rows hit distinct bank slots
+  char *xs = smem;                               // [FH_ROWS][xstride]
+  char *ws = smem + FH_ROWS * xstride;           // [K][chunks*16]
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * FH_ROWS;
+  for (int i = tid; i < FH_ROWS * chunks; i += 256) {
+    const int r = i / chunks, c = i - r * chunks;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m0 + r < M) v = *reinterpret_cast<const uint4 *>(x + (size_t)(m0 + r) * Cin + c * VEC);
+    *reinterpret_cast<uint4 *>(xs + r * xstride + c * 16) = v;
+  }
+  for (int i = tid; i < K * chunks; i += 256)
+    *reinterpret_cast<uint4 *>(ws + (size_t)i * 16) = *reinterpret_cast<const uint4 *>(w + (size_t)i * VEC);
+  __syncthreads();
+  const int r = tid & 63, kg = tid >> 6;
+  const int m = m0 + r;
+  constexpr int KB = 5;                           // k values per pass per thread (k = kg + 4*u)
+  for (int kbase = kg; kbase < K; kbase += 4 * KB) {
+    float acc[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) acc[u] = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+      const uint4 xv = *reinterpret_cast<const uint4 *>(xs + r * xstride + c * 16);
+      const T *xe = reinterpret_cast<const T *>(&xv);
+      float xf[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) xf[e] = Store<T>::ld(xe + e);
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int k = kbase + 4 * u;
+        if (k < K) {
+          const uint4 wv = *reinterpret_cast<const uint4 *>(ws + ((size_t)k * chunks + c) * 16);
+          const T *we = reinterpret_cast<const T *>(&wv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[u] = fmaf(xf[e], Store<T>::ld(we + e), acc[u]);
+        }
+      }
+    }
+    if (m < M) {
+      const int b = m / HW, hw = m - b * HW;
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        const int k = kbase + 4 * u;
+        if (k < K) out[((size_t)b * K + k) * HW + hw] = fminf(fmaxf((acc[u] + bias[k]) / temperature, 0.f), 1.f);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Batched transpose with dtype change: in [B, R, S] -> out [B, S, R].
 // ---------------------------------------------------------------------------
 template <typename TI, typename TO>
@@ -384,6 +449,37 @@ extern "C" int pp_aux_tail(const void *x, const void *w, const float *bias, floa
   else
     return fail("pp_aux_tail: bad dtype %d", dtype);
   PP_CHECK_LAUNCH("aux_tail_kernel");
+  return 0;
+}
+
+extern "C" int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B, int HW,
+                                int Cin, int K, float temperature, int dtype, void *stream) {
+  PP_REQUIRE(B >= 0 && HW > 0 && Cin > 0 && K > 0 && temperature != 0.f, "pp_final_heatmap: bad shape");
+  if (B == 0) return 0;
+  PP_REQUIRE(x && w && bias && out, "pp_final_heatmap: null pointer");
+  PP_REQUIRE(dtype == PP_BF16 || dtype == PP_F32, "pp_final_heatmap: bad dtype %d", dtype);
+  const int es = dtype == PP_BF16 ? 2 : 4, vec = 16 / es;
+  PP_REQUIRE(Cin % vec == 0, "pp_final_heatmap: Cin=%d must be a multiple of %d", Cin, vec);
+  const long long M = (long long)B * HW;
+  PP_REQUIRE(M < (1ll << 31), "pp_final_heatmap: too many rows");
+  const size_t lds = (size_t)FH_ROWS * (Cin / vec + 1) * 16 + (size_t)K * Cin * es;
+  PP_REQUIRE(lds <= 160 * 1024, "pp_final_heatmap: K=%d x Cin=%d does not fit LDS", K, Cin);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = cdiv(M, FH_ROWS);
+  if (dtype == PP_BF16) {
+    if (lds > 64 * 1024)
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_kernel<bf16_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(final_heatmap_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, (const bf16_t *)x,
+                       (const bf16_t *)w, bias, out, (int)M, HW, Cin, K, temperature);
+  } else {
+    if (lds > 64 * 1024)
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_kernel<float>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(final_heatmap_kernel<float>, dim3(grid), dim3(256), lds, s, (const float *)x,
+                       (const float *)w, bias, out, (int)M, HW, Cin, K, temperature);
+  }
+  PP_CHECK_LAUNCH("final_heatmap_kernel");
   return 0;
 }
 

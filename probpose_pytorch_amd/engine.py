@@ -214,6 +214,7 @@ class HeadPlan:
         self.tail_b = _dev(torch.stack(tail_b), device, torch.float32)
         self.ws = _Workspace()
         self._tables: Dict[tuple, dict] = {}
+        self._aux_stream = None
 
     # gather/scatter tables depend on (B, h, w) only
     def _tables_for(self, B: int, h: int, w: int) -> dict:
@@ -253,6 +254,32 @@ class HeadPlan:
         dev, dt, C, K = self.device, self.dtype, self.C, self.K
         tb = self._tables_for(B, h, w)
         g = self.ws.get
+        # ---- aux branches on a second HIP stream: after their first conv they are long-K GEMMs over a
+        # few rows (M = B*16, B*4) that cannot fill 256 CUs; the independent deconvolution branch fills
+        # the idle CUs meanwhile.  Fork/join by events, so the pair is graph-capturable.
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(device=dev)
+        aux = torch.empty((4, B, K), dtype=torch.float32, device=dev)
+        heat = torch.empty((B, K, h * 2 ** len(self.deconvs), w * 2 ** len(self.deconvs)), dtype=torch.float32,
+                           device=dev)
+        self._aux_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self._aux_stream):
+            a, ah, aw = feats, h, w
+            for i, (p, (ro, _, _)) in enumerate(zip(self.pools, tb["aux"])):
+                M = B * ah * aw
+                conv = g(f"aux_conv{i}", (M, 4 * C), dt, dev)
+                if i == 0:
+                    ops.gemm(a, self.aux_w[0], conv, M=M, N=4 * C, Kd=9 * C, lda=C, ldw=9 * C, ldc=4 * C,
+                             bias=self.aux_b[0], rowoff=ro, seg_len=C)
+                else:
+                    ops.gemm(a, self.aux_w[i], conv, M=M, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
+                             bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,
+                             strideC=C, strideBias=C)
+                kh, kw, oh, ow = pack.pool_out(ah, aw, p)
+                pooled = g(f"aux_pool{i}", (B * oh * ow, 4 * C), dt, dev)
+                ops.maxpool_relu(conv, pooled, B, ah, aw, 4 * C, kh, kw)
+                a, ah, aw = pooled, oh, ow
+            ops.aux_tail(a, self.tail_w, self.tail_b, aux, B, C, K)
         # ---- heatmap branch
         x, hh, ww, cin = feats, h, w, C
         for li, (d, (ro, rm, _, _)) in enumerate(zip(self.deconvs, tb["deconv"])):
@@ -270,29 +297,17 @@ class HeadPlan:
                      bias=c["b"], rowoff=ro, seg_len=cin, epilogue=EPI_RELU)
             x, cin = out, c["cout"]
         M = B * hh * ww
-        heat = torch.empty((B, K, hh, ww), dtype=torch.float32, device=dev)
+        assert heat.shape == (B, K, hh, ww)
         f = self.final
         kk = f["k"] * f["k"]
-        ops.gemm(x, f["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=f["b"],
-                 rowoff=tb["final"], seg_len=cin, heatmap=(K, hh * ww, self.temperature))
-        # ---- aux branches
-        a, ah, aw = feats, h, w
-        for i, (p, (ro, _, _)) in enumerate(zip(self.pools, tb["aux"])):
-            M = B * ah * aw
-            conv = g(f"aux_conv{i}", (M, 4 * C), dt, dev)
-            if i == 0:
-                ops.gemm(a, self.aux_w[0], conv, M=M, N=4 * C, Kd=9 * C, lda=C, ldw=9 * C, ldc=4 * C,
-                         bias=self.aux_b[0], rowoff=ro, seg_len=C)
-            else:
-                ops.gemm(a, self.aux_w[i], conv, M=M, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
-                         bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,
-                         strideC=C, strideBias=C)
-            kh, kw, oh, ow = pack.pool_out(ah, aw, p)
-            pooled = g(f"aux_pool{i}", (B * oh * ow, 4 * C), dt, dev)
-            ops.maxpool_relu(conv, pooled, B, ah, aw, 4 * C, kh, kw)
-            a, ah, aw = pooled, oh, ow
-        aux = torch.empty((4, B, K), dtype=torch.float32, device=dev)
-        ops.aux_tail(a, self.tail_w, self.tail_b, aux, B, C, K)
+        es = 2 if dt == torch.bfloat16 else 4
+        if f["k"] == 1 and 64 * (cin * es + 16) + K * cin * es <= 150 * 1024:
+            ops.final_heatmap(x, f["w"], f["b"], heat, B, hh * ww, cin, K, self.temperature)
+        else:
+            ops.gemm(x, f["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=f["b"],
+                     rowoff=tb["final"], seg_len=cin, heatmap=(K, hh * ww, self.temperature))
+        # ---- join the aux-branch stream (forked above)
+        torch.cuda.current_stream(dev).wait_stream(self._aux_stream)
         return (heat, aux[0].reshape(B, K, 1, 1), aux[1].reshape(B, K, 1, 1), aux[2].reshape(B, K, 1, 1),
                 aux[3].reshape(B, K, 1, 1))
 

@@ -26,14 +26,14 @@ def set_profile(sink):
     _PROFILE = sink
 
 
-def _timed(name, work, fn):
+def _timed(name, work, fn, info=""):
     if _PROFILE is None:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
     e.record()
-    _PROFILE.append((name, work, s, e))
+    _PROFILE.append((name, work, s, e, info))
     return r
 
 
@@ -72,7 +72,8 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         a.hm_K, a.hm_HW, a.hm_temperature = heatmap
     a.epilogue = epilogue
     a.tile = tile
-    rc = _timed("gemm", 2.0 * M * N * Kd * batch, lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()))
+    rc = _timed("gemm", 2.0 * M * N * Kd * batch, lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()),
+                f"M={M} N={N} K={Kd} batch={batch} gather={rowoff is not None} epi={epilogue}")
     _lib.check(rc, "pp_gemm")
     return out
 
@@ -117,6 +118,14 @@ def patchify(x, out, patch):
 def maxpool_relu(x, out, B, h, w, Cc, kh, kw):
     _lib.check(_lib.lib().pp_maxpool_relu(_p(x), _p(out), B, h, w, Cc, kh, kw, dtype_code(x.dtype),
                                           _lib.stream_ptr()), "pp_maxpool_relu")
+    return out
+
+
+def final_heatmap(x, w, bias, out, B, HW, Cin, K, temperature):
+    rc = _timed("final_heatmap", float(B * HW * (Cin * x.element_size() + 4 * K)),
+                lambda: _lib.lib().pp_final_heatmap(_p(x), _p(w), _p(bias), _p(out), B, HW, Cin, K,
+                                                    float(temperature), dtype_code(w.dtype), _lib.stream_ptr()))
+    _lib.check(rc, "pp_final_heatmap")
     return out
 
 
