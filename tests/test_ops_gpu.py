@@ -159,6 +159,11 @@ def test_final_heatmap_kernel(ops, dtype, B, HW, Cin, K):
     W = _rand((K, Cin), dtype, 2, Cin ** -0.5)
     b = _rand((K,), torch.float32, 3, 0.1)
     out = torch.empty((B, K, HW), dtype=torch.float32, device="cuda")
+    if 64 * (Cin * x.element_size() + 16) + K * Cin * x.element_size() > 160 * 1024:
+        from probpose_pytorch_amd import _lib
+        with pytest.raises(_lib.HipExtensionError, match="LDS"):   # the engine routes this case to pp_gemm
+            ops.final_heatmap(x, W, b, out, B, HW, Cin, K, 0.5)
+        return
     ops.final_heatmap(x, W, b, out, B, HW, Cin, K, 0.5)
     pre = (x.double() @ W.double().t() + b.double()).reshape(B, HW, K).permute(0, 2, 1)
     torch.testing.assert_close(out.double(), torch.clamp(pre / 0.5, 0, 1), **_tol(dtype, torch.float32))
