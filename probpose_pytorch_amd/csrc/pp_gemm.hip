@@ -75,7 +75,8 @@ struct GemmParams {
   int hm_K, hm_HW;
   float hm_temperature;
   int tiles_m, tiles_n;
-  int blocked;  // XCD-blocked tile order (large grids) vs plain order
+  int blocked;       // XCD-blocked tile order (large grids) vs plain order
+  int lds_epilogue;  // bf16 C tile staged through LDS and stored as whole rows
 };
 
 // LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte offset (M0) + lane * 16.  Issued
@@ -409,6 +410,49 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // the 4 CONSECUTIVE columns n = .. + 4*fq + e -> 8-byte (bf16) / 16-byte (fp32) vector stores.
   // All additive terms are already in the accumulators: activation, convert, store.
   char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
+  if constexpr (sizeof(T) == 2) {
+    // bf16 outputs: stage the C tile through LDS (the K-loop buffers are dead) and store whole rows,
+    // 16 B per lane and BN*2 contiguous bytes per row, instead of 8-B pieces of 16 different rows
+    // per wave-instruction (the direct path's store tail cost ~24 % of a K = 768 tile).
+    constexpr int CS = BN * 2 + 16;                 // padded row stride: keeps 16-B alignment, spreads banks
+    static_assert(BM * CS + BM * 4 <= STAGES * STAGE_BYTES, "C tile must fit the staging buffers");
+    if (p.lds_epilogue) {
+      __syncthreads();                               // every wave is done reading the last K-tile
+      int *rows_lds = reinterpret_cast<int *>(smem + BM * CS);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int lr = wm * (BM / WGM) + i * 16 + frow;
+        if (wn == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (epi & PP_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+          }
+          if (epi & PP_EPI_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<uint2 *>(smem + lr * CS + (wn * (BN / WGN) + j * 16 + fq * 4) * 2) = pk;
+        }
+      }
+      __syncthreads();
+      constexpr int CPR = BN * 2 / 16;               // 16-B chunks per row
+      const int ncols16 = min(CPR, (p.N - n0) / 8);   // N % 8 == 0 on this path
+      for (int c = tid; c < BM * CPR; c += 64 * NW) {
+        const int lr = c / CPR, cc = c - lr * CPR;
+        const int r = rows_lds[lr];
+        if (r < 0 || cc >= ncols16) continue;
+        const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
+        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(Cb) + (size_t)r * p.ldc + n0 + cc * 8) = v;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
@@ -545,6 +589,10 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   const int rn_ = (cfg >= 3) ? 4 : 8;
   const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
   p.blocked = nblk >= 16 ? 1 : 0;
+  p.lds_epilogue = (a->dtype == PP_BF16 && !(a->epilogue & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) && a->N % 8 == 0 &&
+                    a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && (a->strideC % 8) == 0)
+                       ? 1
+                       : 0;
   dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
 #define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
