@@ -410,6 +410,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // the 4 CONSECUTIVE columns n = .. + 4*fq + e -> 8-byte (bf16) / 16-byte (fp32) vector stores.
   // All additive terms are already in the accumulators: activation, convert, store.
   char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
+  bool stored = false;
   if constexpr (sizeof(T) == 2) {
     // bf16 outputs: stage the C tile through LDS (the K-loop buffers are dead) and store whole rows,
     // 16 B per lane and BN*2 contiguous bytes per row, instead of 8-B pieces of 16 different rows
@@ -450,13 +451,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
         const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
         *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(Cb) + (size_t)r * p.ldc + n0 + cc * 8) = v;
       }
-      return;
+      stored = true;
     }
   }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
-    if (m >= p.M) continue;
+    if (stored || m >= p.M) continue;
     const int r = out_row[i];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
