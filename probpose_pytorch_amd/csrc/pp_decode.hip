@@ -30,6 +30,11 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
   return m < n ? m : p - 1 - m;
 }
 
+// single reflection, valid while -n <= i < 2n (always true for |offset| <= radius <= n): no division
+__device__ __forceinline__ int reflect_once(int i, int n) {
+  return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i);
+}
+
 struct Best {
   float v;
   int i;
@@ -141,6 +146,9 @@ __device__ __forceinline__ void conv_passes(float *__restrict__ buf, double *__r
     if (x0 >= R && x0 + 3 + R < W) {
 #pragma unroll
       for (int j = 0; j < WIN; ++j) v[j] = (double)row[x0 - R + j];
+    } else if (W >= R + 3) {   // one reflection suffices (offsets reach at most R + 3 past an edge)
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) v[j] = (double)row[reflect_once(min(x0 - R + j, 2 * W - 1), W)];
     } else {
 #pragma unroll
       for (int j = 0; j < WIN; ++j) v[j] = (double)row[reflect_idx(x0 - R + j, W)];
@@ -168,6 +176,9 @@ __device__ __forceinline__ void conv_passes(float *__restrict__ buf, double *__r
     if (y0 >= R && y0 + 3 + R < H) {
 #pragma unroll
       for (int j = 0; j < WIN; ++j) v[j] = tmp[(y0 - R + j) * W + x];
+    } else if (H >= R + 3) {
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) v[j] = tmp[reflect_once(min(y0 - R + j, 2 * H - 1), H) * W + x];
     } else {
 #pragma unroll
       for (int j = 0; j < WIN; ++j) v[j] = tmp[reflect_idx(y0 - R + j, H) * W + x];

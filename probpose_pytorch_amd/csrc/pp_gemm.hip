@@ -113,7 +113,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 // WGM x WGN waves per workgroup; STAGES LDS buffers (prefetch distance STAGES-1, counted vmcnt).
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES>
+// GATHER: A rows addressed through the row-offset table (implicit convolution).  VEC: N and ldc are
+// multiples of 4 and the epilogue is not the NCHW heatmap store (4-wide vector bias/residual/stores);
+// the ragged variant (VEC = false) keeps the element-wise paths.  Both are compile-time so the hot
+// plain-GEMM instantiation carries none of the gather / scalar code or its registers.
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   const int z = blockIdx.y;
   const char *Ab = p.A + (size_t)z * p.strideA * ES;
   const char *Wb = p.W + (size_t)z * p.strideW * ES;
-  const int32_t *rowoff = p.rowoff ? p.rowoff + (size_t)z * p.strideRowoff : nullptr;
+  const int32_t *rowoff = GATHER ? p.rowoff + (size_t)z * p.strideRowoff : nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave - wm * WGN;
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   int cur_off[PA], nxt_off[PA];
 #pragma unroll
   for (int j = 0; j < PA; ++j) cur_off[j] = nxt_off[j] = 0;
-  if (rowoff) {
+  if constexpr (GATHER) {
 #pragma unroll
     for (int j = 0; j < PA; ++j) cur_off[j] = rowoff[a_row[j]];
   }
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
     st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
     st_koff = (size_t)kt * ROW_BYTES;
-    if (rowoff) {
+    if constexpr (GATHER) {
       const int k0 = kt * BK;
       const int seg = k0 / p.seg_len;
       st_kin = k0 - seg * p.seg_len;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     constexpr int q = decltype(qc)::value;
     if constexpr (q < PA) {
       const char *src;
-      if (rowoff)
+      if constexpr (GATHER)
         src = cur_off[q] >= 0 ? Ab + ((size_t)cur_off[q] + st_kin) * ES + lchunk_off
                               : zero_line + (q & 7) * 1024;
       else
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     }
   };
   auto stage_end = [&](int kt) {
-    if (rowoff) {
+    if constexpr (GATHER) {
       const int k0 = kt * BK;
       const int seg = k0 / p.seg_len;
       if (st_kin + BK == p.seg_len && k0 + BK < p.Kd) {
@@ -316,48 +320,55 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   const float *__restrict__ bias = p.bias ? p.bias + (size_t)z * p.strideBias : nullptr;
   const int32_t *__restrict__ rowmap = p.out_rowmap ? p.out_rowmap + (size_t)z * p.strideRowmap : nullptr;
   const float *Rb = p.residual ? p.residual + (size_t)z * p.strideC : nullptr;
-  const bool vec_ok = (p.N & 3) == 0 && (p.ldc & 3) == 0 && !(epi & PP_EPI_HEATMAP);
+  constexpr bool vec_ok = VEC;
   int out_row[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
     out_row[i] = (rowmap && m < p.M) ? rowmap[m] : m;
   }
+  // one row-shaped term goes straight into the accumulator registers (no extra live registers):
+  // the residual (proj / fc2) or the pos-embed row bias (patch embed); the column bias is added
+  // from TN float4 registers in the epilogue.
+  const float *init_base = (epi & PP_EPI_RESIDUAL) ? Rb : ((epi & PP_EPI_ROWBIAS) ? p.rowbias : nullptr);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
+    const size_t rowbase = (epi & PP_EPI_RESIDUAL) ? (size_t)out_row[i] * p.ldc
+                                                   : (size_t)(m % (p.rowbias_period > 0 ? p.rowbias_period : 1)) * p.ldc;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
       f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) {
-        if (vec_ok) {
+      if (init_base && m < p.M) {
+        if constexpr (vec_ok) {
           if (n < p.N) {
-            if (epi & PP_EPI_BIAS) {
-              const float4 t = *reinterpret_cast<const float4 *>(bias + n);
-              c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += t.w;
-            }
-            if (epi & PP_EPI_ROWBIAS) {
-              const float4 t = *reinterpret_cast<const float4 *>(p.rowbias + (size_t)(m % p.rowbias_period) * p.ldc + n);
-              c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += t.w;
-            }
-            if (epi & PP_EPI_RESIDUAL) {
-              const float4 t = *reinterpret_cast<const float4 *>(Rb + (size_t)out_row[i] * p.ldc + n);
-              c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += t.w;
-            }
+            const float4 t = *reinterpret_cast<const float4 *>(init_base + rowbase + n);
+            c = f32x4{t.x, t.y, t.z, t.w};
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e < p.N) {
-              if (epi & PP_EPI_BIAS) c[e] += bias[n + e];
-              if (epi & PP_EPI_ROWBIAS) c[e] += p.rowbias[(size_t)(m % p.rowbias_period) * p.ldc + n + e];
-              if ((epi & PP_EPI_RESIDUAL) && !(epi & PP_EPI_HEATMAP)) c[e] += Rb[(size_t)out_row[i] * p.ldc + n + e];
-            }
-          }
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) c[e] = init_base[rowbase + n + e];
         }
       }
       acc[i][j] = c;
+    }
+  }
+  float4 bias4[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
+    bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (epi & PP_EPI_BIAS) {
+      if constexpr (vec_ok) {
+        if (n < p.N) bias4[j] = *reinterpret_cast<const float4 *>(bias + n);
+      } else {
+        if (n + 0 < p.N) bias4[j].x = bias[n + 0];
+        if (n + 1 < p.N) bias4[j].y = bias[n + 1];
+        if (n + 2 < p.N) bias4[j].z = bias[n + 2];
+        if (n + 3 < p.N) bias4[j].w = bias[n + 3];
+      }
     }
   }
 
@@ -375,28 +386,40 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // the loads above (bias, row map) are older than every DMA piece: retire them once, here, so that
   // inside the loop only DMA pieces are outstanding and the counted waits are exact
   PP_STAMP(t_pro);
-  int buf = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
+  int buf = 0, kt = 0;
+  // steady state: every iteration prefetches tile kt + STAGES - 1 (one code path in the loop body,
+  // so the accumulators stay in place across iterations)
+  for (; kt + STAGES - 1 < nkt; ++kt) {
+    PP_STAMP(ta);
+    wait_vmcnt<(STAGES - 2) * PIECES>();          // STAGES-2 younger tiles may still fly
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_STAMP(tb);
+    __builtin_amdgcn_s_barrier();
+    PP_STAMP(tc);
+    int nb = buf + STAGES - 1;
+    if (nb >= STAGES) nb -= STAGES;
+    stage_begin(kt + STAGES - 1, nb);
+    compute(buf, std::true_type{});
+    stage_end(kt + STAGES - 1);
+    PP_STAMP(te);
+    PP_ACC(c_bar, tb, tc);
+    PP_ACC(c_wait, ta, tb);
+    PP_ACC(c_comp, tc, te);
+    if (++buf == STAGES) buf = 0;
+  }
+  // tail: the last STAGES-1 tiles are already in flight, nothing left to prefetch
+  for (; kt < nkt; ++kt) {
     PP_STAMP(ta);
     if (kt + STAGES - 1 <= nkt) {
-      wait_vmcnt<(STAGES - 2) * PIECES>();        // steady state: STAGES-2 younger tiles may still fly
+      wait_vmcnt<(STAGES - 2) * PIECES>();
     } else {
-      wait_vmcnt<0>();                            // drain at the tail (fewer tiles were issued)
+      wait_vmcnt<0>();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PP_STAMP(tb);
     __builtin_amdgcn_s_barrier();
     PP_STAMP(tc);
-    const int nt = kt + STAGES - 1;
-    if (nt < nkt) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      stage_begin(nt, nb);
-      compute(buf, std::true_type{});
-      stage_end(nt);
-    } else {
-      compute(buf, std::false_type{});
-    }
+    compute(buf, std::false_type{});
     PP_STAMP(te);
     PP_ACC(c_bar, tb, tc);
     PP_ACC(c_wait, ta, tb);
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // All additive terms are already in the accumulators: activation, convert, store.
   char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
   bool stored = false;
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) == 2 && VEC) {
     // bf16 outputs: stage the C tile through LDS (the K-loop buffers are dead) and store whole rows,
     // 16 B per lane and BN*2 contiguous bytes per row, instead of 8-B pieces of 16 different rows
     // per wave-instruction (the direct path's store tail cost ~24 % of a K = 768 tile).
@@ -426,7 +449,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
         if (wn == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                        acc[i][j][3] + bias4[j].w};
           if (epi & PP_EPI_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
@@ -463,7 +487,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
       if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                    acc[i][j][3] + bias4[j].w};
       if (epi & PP_EPI_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
@@ -472,7 +497,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      if (vec_ok) {
+      if constexpr (vec_ok) {
         const size_t idx = (size_t)r * p.ldc + n;
         if ((epi & PP_EPI_OUT_F32) || sizeof(T) == 4) {
           *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Cb) + idx) = make_float4(v[0], v[1], v[2], v[3]);
@@ -482,8 +507,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
           pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
           *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(Cb) + idx) = pk;
         }
-        continue;
-      }
+      } else {
       // scalar path: ragged N (e.g. the K=17 heatmap layer) or unaligned ldc
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -502,6 +526,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
         else
           Store<T>::st(reinterpret_cast<T *>(Cb) + idx, x);
       }
+      }
     }
   }
 #ifdef PP_GEMM_STAMPS
@@ -517,6 +542,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
 
 }  // namespace pp
 
+#ifndef PP_CFG5_VS_CFG3
+#define PP_CFG5_VS_CFG3 1.0
+#endif
 #ifndef PP_CFG3_SPEEDUP
 #define PP_CFG3_SPEEDUP 1.3  // measured: one 8-wave 3-stage 192x192 tile per CU vs two co-resident 4-wave tiles
 #endif
@@ -564,15 +592,16 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   const int batch = a->batch > 0 ? a->batch : 1;
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
-  // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages; N = 256
-  // layers).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
+  // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages),
+  // 5 = 384x128 (8 waves, 2 stages; the N = 256 deconvolution layers).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 4, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 5, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
   };
-  int cfg = a->tile;
+  const bool vec = (a->N & 3) == 0 && (a->ldc & 3) == 0 && !(a->epilogue & PP_EPI_HEATMAP);
+  int cfg = vec ? a->tile : 1;
   if (cfg == 0) {
     const double c1 = (double)rounds(128, 128, 512) * 128 * 128 * 2;   // 2 workgroups share a CU
     const double c2 = (double)rounds(192, 96, 512) * 192 * 96 * 2;
@@ -583,8 +612,13 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     if (c2 < best) { best = c2; cfg = 2; }
     if (c4 < best) { best = c4; cfg = 4; }
     if (c3 <= best) { best = c3; cfg = 3; }
+    if (a->N <= 256) {  // narrow outputs (deconvolution layers): a taller tile restores the flop/byte ratio
+      const double c5 = (double)rounds(384, 128, 256) * 384 * 128 / (PP_CFG3_SPEEDUP * PP_CFG5_VS_CFG3);
+      if (c5 < best) { best = c5; cfg = 5; }
+    }
   }
-  const int bm = cfg == 1 ? 128 : 192, bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : (cfg == 3 ? 192 : 128));
+  const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : 192);
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : (cfg == 3 ? 192 : 128));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   const int rn_ = (cfg >= 3) ? 4 : 8;
@@ -596,30 +630,47 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                        : 0;
   dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
-#define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
+#define PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_)                                         \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
     static thread_local bool attr = false;                                                            \
     if (!attr) {                                                                                      \
       PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
-          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_>),                  \
+          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_>),          \
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
       attr = true;                                                                                    \
     }                                                                                                 \
-    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_>), grid, dim3(64 * WGM_ * WGN_), lds, \
-                       s, p);                                                                         \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_>), grid,                     \
+                       dim3(64 * WGM_ * WGN_), lds, s, p);                                            \
   } while (0)
-  if (a->dtype == PP_BF16) {
+#define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
+  do {                                                                                                \
+    if (gather) PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, true, true);                           \
+    else PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, false, true);                                 \
+  } while (0)
+  const bool gather = a->rowoff != nullptr;
+  if (!vec) {  // ragged N / heatmap epilogue: element-wise variant, 128x128 only
+    if (a->dtype == PP_BF16) {
+      if (gather) PP_LAUNCH_GEMM_V(bf16_t, 128, 128, 2, 2, 2, true, false);
+      else PP_LAUNCH_GEMM_V(bf16_t, 128, 128, 2, 2, 2, false, false);
+    } else {
+      if (gather) PP_LAUNCH_GEMM_V(float, 128, 128, 2, 2, 2, true, false);
+      else PP_LAUNCH_GEMM_V(float, 128, 128, 2, 2, 2, false, false);
+    }
+  } else if (a->dtype == PP_BF16) {
     if (cfg == 1) PP_LAUNCH_GEMM(bf16_t, 128, 128, 2, 2, 2);
     else if (cfg == 2) PP_LAUNCH_GEMM(bf16_t, 192, 96, 2, 2, 2);
     else if (cfg == 3) PP_LAUNCH_GEMM(bf16_t, 192, 192, 2, 4, 3);
-    else PP_LAUNCH_GEMM(bf16_t, 192, 128, 2, 4, 3);
+    else if (cfg == 4) PP_LAUNCH_GEMM(bf16_t, 192, 128, 2, 4, 3);
+    else PP_LAUNCH_GEMM(bf16_t, 384, 128, 2, 4, 2);
   } else {
     if (cfg == 1) PP_LAUNCH_GEMM(float, 128, 128, 2, 2, 2);
     else if (cfg == 2) PP_LAUNCH_GEMM(float, 192, 96, 2, 2, 2);
     else if (cfg == 3) PP_LAUNCH_GEMM(float, 192, 192, 2, 4, 3);
-    else PP_LAUNCH_GEMM(float, 192, 128, 2, 4, 3);
+    else if (cfg == 4) PP_LAUNCH_GEMM(float, 192, 128, 2, 4, 3);
+    else PP_LAUNCH_GEMM(float, 384, 128, 2, 4, 2);
   }
+#undef PP_LAUNCH_GEMM_V
 #undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");
   return 0;

@@ -34,18 +34,20 @@ def main():
                                    ("fc1+gelu", 3072, 768, ops.EPI_GELU, False), ("fc1 nogelu", 3072, 768, 0, False),
                                    ("fc1 relu", 3072, 768, ops.EPI_RELU, False),
                                    ("fc2", 768, 3072, 0, True), ("fc2 noresid", 768, 3072, 0, False),
+                                   ("deconv0-like N256 K3072", 256, 3072, ops.EPI_RELU, False),
+                                   ("deconv1-like M49152 N256 K1024", 256, 1024, ops.EPI_RELU, False),
                                    ("big 4096x4096x4096", 4096, 4096, 0, False)]:
-        Mm = 4096 if name.startswith("big") else M
+        Mm = 4096 if name.startswith("big") else (49152 if "M49152" in name else M)
         A = torch.randn((Mm, K), generator=gen).to(dt).cuda()
         W = (torch.randn((N, K), generator=gen) * K ** -0.5).to(dt).cuda()
         b = torch.randn((N,), generator=gen).cuda()
         res = torch.randn((Mm, N), generator=gen).cuda() if resid else None
         out = res if resid else torch.empty((Mm, N), dtype=dt, device="cuda")
-        for tile in (1, 2, 3):
+        for tile in (3, 4, 5):
             t = bench(lambda: ops.linear(A, W, b, out=out, epilogue=epi, residual=res, tile=tile))
             rows.append((name, tile, t, 2.0 * Mm * N * K / t / 1e6))
     for r in rows:
-        print(f"{r[0]:22s} tile={r[1]}  {r[2]:8.1f} us  {r[3]:7.1f} TFLOP/s")
+        print(f"{r[0]:32s} tile={r[1]}  {r[2]:8.1f} us  {r[3]:7.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
