@@ -8,7 +8,9 @@
 //                    axis, so a query's scores sit in one lane quartet and the
 //                    row max / sum is 47 in-lane ops + 2 shuffles;
 //   P^T stays in the accumulator registers and is fed straight back as the B
-//                    operand of the second product (no LDS round trip);
+//                    operand of the second product (no LDS round trip); the keys are
+//                    processed as two blocks of 96 with an online-softmax rescale so
+//                    that three workgroups fit a CU;
 //   O^T = V^T P^T    V is transposed once while being staged into LDS.
 // The k-slot order inside each 32-key MFMA step is permuted identically on both
 // operands (slot (g,j) <-> key 4g + j for j < 4, 16 + 4g + (j-4) otherwise),
@@ -37,7 +39,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
-__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t *__restrict__ qkv,
+__global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__restrict__ qkv,
                                                                 bf16_t *__restrict__ out, int N,
                                                                 int heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,84 +87,104 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t *__
   }
   __syncthreads();
 
-  // ---- S^T = K Q^T : acc[kt][t] rows = keys 16*kt + 4g + r, col = query q0 + 16t + lrow
-  f32x4 sacc[AT_NT][AT_QT];
+  // ---- two key blocks of 96 keys, flash style: only 6 x QT score tiles (72 registers) are live at a
+  // time, which lets three workgroups share a CU (768 (crop, head) problems = one full round of
+  // 256 CUs x 3 instead of 1.5 rounds of 2).  Running max m, per-lane partial sum l, and the output
+  // accumulator are rescaled by alpha = exp2((m_old - m_new) * c) between the blocks.
+  constexpr int KB_TILES = AT_NT / 2;  // 6 key tiles per block
+  float m_run[AT_QT], l_run[AT_QT];
+  f32x4 oacc[4][AT_QT];
 #pragma unroll
-  for (int kt = 0; kt < AT_NT; ++kt)
+  for (int t = 0; t < AT_QT; ++t) {
+    m_run[t] = -__builtin_inff();
+    l_run[t] = 0.f;
 #pragma unroll
-    for (int t = 0; t < AT_QT; ++t) sacc[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < 4; ++dt) oacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
-  for (int kt = 0; kt < AT_NT; ++kt) {
-    const int r = kt * 16 + lrow;
+  for (int kb = 0; kb < 2; ++kb) {
+    // S^T block = K_block Q^T : sacc[kt][t] rows = keys 96*kb + 16*kt + 4g + r, col = query
+    f32x4 sacc[KB_TILES][AT_QT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const uint4 kf = *reinterpret_cast<const uint4 *>(Ks + r * AT_KROW + (((4 * s + g) ^ (r & 7)) << 4));
+    for (int kt = 0; kt < KB_TILES; ++kt) {
 #pragma unroll
-      for (int t = 0; t < AT_QT; ++t)
-        sacc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&kf),
-                                                              *reinterpret_cast<const bf16x8 *>(&qf[t][s]),
-                                                              sacc[kt][t], 0, 0, 0);
+      for (int t = 0; t < AT_QT; ++t) sacc[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int r = (kb * KB_TILES + kt) * 16 + lrow;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const uint4 kf = *reinterpret_cast<const uint4 *>(Ks + r * AT_KROW + (((4 * s + g) ^ (r & 7)) << 4));
+#pragma unroll
+        for (int t = 0; t < AT_QT; ++t)
+          sacc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&kf),
+                                                                *reinterpret_cast<const bf16x8 *>(&qf[t][s]),
+                                                                sacc[kt][t], 0, 0, 0);
+      }
+    }
+    // online softmax over this block's keys, per query column
+#pragma unroll
+    for (int t = 0; t < AT_QT; ++t) {
+      float mb = -__builtin_inff();
+#pragma unroll
+      for (int kt = 0; kt < KB_TILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (kb * KB_TILES + kt) * 16 + g * 4 + r;
+          if (key >= N) sacc[kt][t][r] = -__builtin_inff();
+          mb = fmaxf(mb, sacc[kt][t][r]);
+        }
+      mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+      mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+      const float m_new = fmaxf(m_run[t], mb);          // finite: block 0 always holds key 0
+      const float alpha = exp2f((m_run[t] - m_new) * scale_log2e);  // block 0: exp2(-inf) = 0
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KB_TILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = exp2f((sacc[kt][t][r] - m_new) * scale_log2e);
+          sacc[kt][t][r] = pv;
+          l += pv;
+        }
+      l_run[t] = l_run[t] * alpha + l;
+      m_run[t] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        oacc[dt][t][0] *= alpha; oacc[dt][t][1] *= alpha; oacc[dt][t][2] *= alpha; oacc[dt][t][3] *= alpha;
+      }
+    }
+    // O^T += V_block^T P_block^T : rows = dims 16*dt + 4g + r, col = query
+#pragma unroll
+    for (int u = 0; u < KB_TILES / 2; ++u) {  // 32 keys per step
+      uint4 pf[AT_QT];
+#pragma unroll
+      for (int t = 0; t < AT_QT; ++t) {
+        pf[t].x = pack_bf16x2(sacc[2 * u][t][0], sacc[2 * u][t][1]);
+        pf[t].y = pack_bf16x2(sacc[2 * u][t][2], sacc[2 * u][t][3]);
+        pf[t].z = pack_bf16x2(sacc[2 * u + 1][t][0], sacc[2 * u + 1][t][1]);
+        pf[t].w = pack_bf16x2(sacc[2 * u + 1][t][2], sacc[2 * u + 1][t][3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const char *vrow = Vt + (dt * 16 + lrow) * AT_VROW + (kb * (KB_TILES * 16) + 32 * u + 4 * g) * 2;
+        uint4 vf;
+        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
+        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 32);
+        vf.x = lo.x; vf.y = lo.y; vf.z = hi.x; vf.w = hi.y;
+#pragma unroll
+        for (int t = 0; t < AT_QT; ++t)
+          oacc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&vf),
+                                                                *reinterpret_cast<const bf16x8 *>(&pf[t]),
+                                                                oacc[dt][t], 0, 0, 0);
+      }
     }
   }
-
-  // ---- softmax over keys, per query column (in-lane over 48 values, then across the 4 lane groups)
   float inv_l[AT_QT];
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
-    float m = -__builtin_inff();
-#pragma unroll
-    for (int kt = 0; kt < AT_NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        if (key >= N) sacc[kt][t][r] = -__builtin_inff();
-        m = fmaxf(m, sacc[kt][t][r]);
-      }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < AT_NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = exp2f((sacc[kt][t][r] - m) * scale_log2e);
-        sacc[kt][t][r] = p;
-        l += p;
-      }
+    float l = l_run[t];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     inv_l[t] = 1.0f / l;
-  }
-
-  // ---- O^T = V^T P^T : rows = dims 16*dt + 4g + r, col = query
-  f32x4 oacc[4][AT_QT];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int t = 0; t < AT_QT; ++t) oacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int u = 0; u < AT_NT / 2; ++u) {  // 32 keys per step
-    uint4 pf[AT_QT];
-#pragma unroll
-    for (int t = 0; t < AT_QT; ++t) {
-      pf[t].x = pack_bf16x2(sacc[2 * u][t][0], sacc[2 * u][t][1]);
-      pf[t].y = pack_bf16x2(sacc[2 * u][t][2], sacc[2 * u][t][3]);
-      pf[t].z = pack_bf16x2(sacc[2 * u + 1][t][0], sacc[2 * u + 1][t][1]);
-      pf[t].w = pack_bf16x2(sacc[2 * u + 1][t][2], sacc[2 * u + 1][t][3]);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const char *vrow = Vt + (dt * 16 + lrow) * AT_VROW + (32 * u + 4 * g) * 2;
-      uint4 vf;
-      const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-      const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 32);
-      vf.x = lo.x; vf.y = lo.y; vf.z = hi.x; vf.w = hi.y;
-#pragma unroll
-      for (int t = 0; t < AT_QT; ++t)
-        oacc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&vf),
-                                                              *reinterpret_cast<const bf16x8 *>(&pf[t]),
-                                                              oacc[dt][t], 0, 0, 0);
-    }
   }
 
   // ---- store: lane holds 4 consecutive dims of one query -> 8-byte stores
