@@ -11,7 +11,8 @@
 //                    operand of the second product (no LDS round trip); the keys are
 //                    processed as two blocks of 96 with an online-softmax rescale so
 //                    that three workgroups fit a CU;
-//   O^T = V^T P^T    V is transposed once while being staged into LDS.
+//   O^T = V^T P^T    V stays row-major in LDS and is read transposed by
+//                    ds_read_b64_tr_b16 (one 4-key x 16-dim block per 16-lane group).
 // The k-slot order inside each 32-key MFMA step is permuted identically on both
 // operands (slot (g,j) <-> key 4g + j for j < 4, 16 + 4g + (j-4) otherwise),
 // which is what makes the accumulator directly reusable.
@@ -31,9 +32,34 @@ constexpr int AT_HD = 64;
 constexpr int AT_NMAX = 192;              // keys / queries held on chip
 constexpr int AT_NT = AT_NMAX / 16;       // 12 key tiles
 constexpr int AT_QT = 3;                  // query tiles (16 rows) per wave
-constexpr int AT_KROW = AT_HD * 2;        // 128 B per K row in LDS
-constexpr int AT_VROW = (AT_NMAX + 8) * 2;  // V^T row: 192 keys + 8 pad (bank spread), bytes
-constexpr int AT_LDS = AT_NMAX * AT_KROW + AT_HD * AT_VROW;  // 24576 + 25600
+constexpr int AT_KROW = AT_HD * 2;        // 128 B per K / V row in LDS
+constexpr int AT_LDS = 2 * AT_NMAX * AT_KROW;  // K + V, row-major, 48 KiB
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Diagnostic build only (-DPP_ATT_STAMPS): phase cycle counts of wave 0 go behind the output tensor.
+#ifdef PP_ATT_STAMPS
+__device__ __forceinline__ unsigned long long att_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define ATT_STAMP(v) const unsigned long long v = att_stamp()
+#else
+#define ATT_STAMP(v)
+#endif
+
+__device__ __attribute__((aligned(256))) unsigned char g_att_zero[1024];
+
+__device__ __forceinline__ void att_glds16(const void *gsrc, unsigned lds_off_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_off_uniform)
+      : "memory");
+}
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
@@ -44,33 +70,30 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
                                                                 int heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Ks = smem;                          // [192][64] bf16, 16-B chunks XOR-swizzled by (row & 7)
-  char *Vt = smem + AT_NMAX * AT_KROW;      // [64][200] bf16 (V transposed)
+  char *Vs = smem + AT_NMAX * AT_KROW;      // [192][64] bf16, same layout; read transposed (ds_read_b64_tr_b16)
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const int C = heads * AT_HD, ld = 3 * C;
   const bf16_t *base = qkv + (size_t)b * N * ld + h * AT_HD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, g = lane >> 4;
 
-  // ---- stage K (row-major, swizzled) and V (transposed) into LDS; rows >= N are zero
-  for (int i = tid; i < AT_NMAX * 8; i += 256) {  // K: 192 rows x 8 chunks of 16 B
-    const int r = i >> 3, c = i & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < N) v = *reinterpret_cast<const uint4 *>(base + (size_t)r * ld + C + c * 8);
-    *reinterpret_cast<uint4 *>(Ks + r * AT_KROW + ((c ^ (r & 7)) << 4)) = v;
-  }
-  // V: (key pair, 8-dim chunk) items; consecutive lanes take consecutive key pairs so the transposed
-  // 32-bit stores of one wave-instruction spread over all 32 LDS banks (2-way, free).
-  for (int i = tid; i < (AT_NMAX / 2) * 8; i += 256) {
-    const int c = i / (AT_NMAX / 2), kp = i - c * (AT_NMAX / 2);
-    const int k0 = 2 * kp;
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-    if (k0 < N) v0 = *reinterpret_cast<const uint4 *>(base + (size_t)k0 * ld + 2 * C + c * 8);
-    if (k0 + 1 < N) v1 = *reinterpret_cast<const uint4 *>(base + (size_t)(k0 + 1) * ld + 2 * C + c * 8);
-    const unsigned short *a = reinterpret_cast<const unsigned short *>(&v0);
-    const unsigned short *bb = reinterpret_cast<const unsigned short *>(&v1);
+  ATT_STAMP(t0);
+  // ---- stage K and V into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 24 one-KiB
+  // pieces per wave issued back to back, one wait), both row-major; the 16-B chunk XOR swizzle is
+  // applied on the per-lane SOURCE address so the LDS image stays lane-linear.  Rows >= N read a
+  // zero line.  V is NOT transposed here: the second product reads it through ds_read_b64_tr_b16.
+  {
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+    const int prow = lane >> 3, pchunk = lane & 7;
 #pragma unroll
-    for (int e = 0; e < 8; ++e)  // Vt[d][k0], Vt[d][k0+1] as one 32-bit store
-      *reinterpret_cast<unsigned *>(Vt + (c * 8 + e) * AT_VROW + k0 * 2) = (unsigned)a[e] | ((unsigned)bb[e] << 16);
+    for (int j = 0; j < AT_NMAX / 8 / 4; ++j) {          // 6 pieces of 8 rows per wave, for K and for V
+      const int r = (wave * (AT_NMAX / 8 / 4) + j) * 8 + prow;
+      const int lchunk = pchunk ^ (r & 7);
+      const bf16_t *src = (r < N) ? base + (size_t)r * ld + lchunk * 8 : nullptr;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (wave * (AT_NMAX / 8 / 4) + j) * 1024);
+      att_glds16(src ? (const void *)(src + C) : (const void *)(g_att_zero + lane * 16), dst);
+      att_glds16(src ? (const void *)(src + 2 * C) : (const void *)(g_att_zero + lane * 16), dst + AT_NMAX * AT_KROW);
+    }
   }
 
   // ---- Q fragments straight from global: B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]
@@ -85,7 +108,10 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       if (q < N) qf[t][s] = *reinterpret_cast<const uint4 *>(base + (size_t)q * ld + s * 32 + g * 8);
     }
   }
+  ATT_STAMP(t1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (and the Q loads) have landed
   __syncthreads();
+  ATT_STAMP(t2);
 
   // ---- two key blocks of 96 keys, flash style: only 6 x QT score tiles (72 registers) are live at a
   // time, which lets three workgroups share a CU (768 (crop, head) problems = one full round of
@@ -107,8 +133,12 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
     f32x4 sacc[KB_TILES][AT_QT];
 #pragma unroll
     for (int kt = 0; kt < KB_TILES; ++kt) {
+      // keys >= N (zero rows in LDS) start at -inf, so their scores stay -inf and their weights 0
+      const int key_lo = (kb * KB_TILES + kt) * 16 + g * 4;
+      const f32x4 init = f32x4{key_lo + 0 < N ? 0.f : -__builtin_inff(), key_lo + 1 < N ? 0.f : -__builtin_inff(),
+                               key_lo + 2 < N ? 0.f : -__builtin_inff(), key_lo + 3 < N ? 0.f : -__builtin_inff()};
 #pragma unroll
-      for (int t = 0; t < AT_QT; ++t) sacc[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < AT_QT; ++t) sacc[kt][t] = init;
       const int r = (kb * KB_TILES + kt) * 16 + lrow;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -120,28 +150,26 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
                                                                 sacc[kt][t], 0, 0, 0);
       }
     }
-    // online softmax over this block's keys, per query column
+    // online softmax over this block's keys, per query column.  VALU diet (this phase, not the MFMAs,
+    // bounds the kernel): padded keys are masked through the accumulator init (below), scores are
+    // pre-scaled by c = log2(e)/sqrt(hd) so each probability is one FMA + one raw v_exp_f32.
 #pragma unroll
     for (int t = 0; t < AT_QT; ++t) {
-      float mb = -__builtin_inff();
+      float mb = sacc[0][t][0];
 #pragma unroll
       for (int kt = 0; kt < KB_TILES; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = (kb * KB_TILES + kt) * 16 + g * 4 + r;
-          if (key >= N) sacc[kt][t][r] = -__builtin_inff();
-          mb = fmaxf(mb, sacc[kt][t][r]);
-        }
+        for (int r = 0; r < 4; ++r) mb = fmaxf(mb, sacc[kt][t][r]);
       mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
       mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
-      const float m_new = fmaxf(m_run[t], mb);          // finite: block 0 always holds key 0
-      const float alpha = exp2f((m_run[t] - m_new) * scale_log2e);  // block 0: exp2(-inf) = 0
+      const float m_new = fmaxf(m_run[t], mb * scale_log2e);   // running max of the SCALED scores; finite
+      const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);  // block 0: exp2(-inf) = 0
       float l = 0.f;
 #pragma unroll
       for (int kt = 0; kt < KB_TILES; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f((sacc[kt][t][r] - m_new) * scale_log2e);
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], scale_log2e, -m_new));
           sacc[kt][t][r] = pv;
           l += pv;
         }
@@ -165,11 +193,25 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const char *vrow = Vt + (dt * 16 + lrow) * AT_VROW + (kb * (KB_TILES * 16) + 32 * u + 4 * g) * 2;
+        // A operand = V^T fragment: lane (dim = lrow, g) needs keys {4g..4g+3} and {16+4g..16+4g+3}
+        // of this 32-key step for its dim.  Each 16-lane group g issues one transposing read per key
+        // quartet: lane 4q+p of the group addresses row (key) q, dims 4p..4p+3 of the 16-dim block;
+        // lane i receives dim i of the 4 keys.  (EXEC is all ones here; addresses are 8-B aligned.)
+        const int tq = lrow >> 2, tp = lrow & 3;
+        const int key0 = kb * (KB_TILES * 16) + 32 * u + 4 * g + tq;
+        const int ch = 2 * dt + (tp >> 1);
+        const int a0 = key0 * AT_KROW + ((ch ^ (key0 & 7)) << 4) + (tp & 1) * 8;
+        const int key1 = key0 + 16;
+        const int a1 = key1 * AT_KROW + ((ch ^ (key1 & 7)) << 4) + (tp & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(Vs + a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(Vs + a1));
         uint4 vf;
-        const uint2 lo = *reinterpret_cast<const uint2 *>(vrow);
-        const uint2 hi = *reinterpret_cast<const uint2 *>(vrow + 32);
-        vf.x = lo.x; vf.y = lo.y; vf.z = hi.x; vf.w = hi.y;
+        vf.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        vf.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        vf.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        vf.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
 #pragma unroll
         for (int t = 0; t < AT_QT; ++t)
           oacc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&vf),
@@ -178,6 +220,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       }
     }
   }
+  ATT_STAMP(t3);
   float inv_l[AT_QT];
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
@@ -201,6 +244,15 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       *reinterpret_cast<uint2 *>(orow + dt * 16 + g * 4) = pk;
     }
   }
+#ifdef PP_ATT_STAMPS
+  {
+    ATT_STAMP(t4);
+    if (tid == 0) {
+      unsigned long long *o = reinterpret_cast<unsigned long long *>(out + (size_t)gridDim.x / heads * N * C) + (size_t)blockIdx.x * 8;
+      o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3; o[4] = t4 - t0; o[5] = t0;
+    }
+  }
+#endif
 }
 
 }  // namespace pp
