@@ -117,16 +117,23 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // multiples of 4 and the epilogue is not the NCHW heatmap store (4-wide vector bias/residual/stores);
 // the ragged variant (VEC = false) keeps the element-wise paths.  Both are compile-time so the hot
 // plain-GEMM instantiation carries none of the gather / scalar code or its registers.
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
+//
+// NWP > 0 selects the wave-specialised form: WGM x WGN consumer waves that only read fragments and
+// issue MFMAs, plus NWP producer waves that only issue the LDS-DMA pieces.  A global_load_lds
+// blocks its wave for ~100-200 cycles while the CU's address unit drains (measured); with the DMA
+// on the MFMA-issuing waves that stall came straight out of the matrix pipe's issue time.
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0>
+__global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = ROW_BYTES / ES;  // elements of K per tile
-  constexpr int NW = WGM * WGN;
-  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;    // 1-KiB DMA pieces (8 rows) per wave per K-tile
+  constexpr int NW = WGM * WGN;                         // consumer (MFMA) waves
+  constexpr int NWS = NWP > 0 ? NWP : NW;               // waves that issue the DMA
+  constexpr int NTHREADS = 64 * (NW + NWP);
+  constexpr int PA = BM / 8 / NWS, PB = BN / 8 / NWS;  // 1-KiB DMA pieces (8 rows) per staging wave per K-tile
   constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;  // 16x16 MFMA tiles per wave
   constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0, "tile");
+  static_assert(BM % (8 * NWS) == 0 && BN % (8 * NWS) == 0 && BM % (16 * WGM) == 0 && BN % (16 * WGN) == 0, "tile");
 
   // ---- tile assignment, XCD-aware (speed only, never correctness): workgroups b and b+8 share an
   // XCD and its 4 MiB L2.  The tile grid is cut into blocks of 8 x RN tiles (one block = one round
@@ -155,27 +162,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   const int32_t *rowoff = GATHER ? p.rowoff + (size_t)z * p.strideRowoff : nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const bool is_producer = NWP > 0 && __builtin_amdgcn_readfirstlane(wave) >= NW;
+  const int cw = is_producer ? 0 : wave;               // consumer index (producers never use wm / wn)
+  const int wm = cw / WGN, wn = cw - wm * WGN;
+  const int sw = NWP > 0 ? (is_producer ? wave - NW : 0) : wave;  // staging-wave index
 
   // ---- staging geometry: each wave issues PA A-pieces + PB W-pieces (8 rows x 128 B) per K-tile.
   // lane -> (row in piece, physical 16-B chunk); logical chunk = physical ^ (row & 7).
   const int prow = lane >> 3, pchunk = lane & 7;
   // this lane's line inside the zero region: spread over workgroups, waves and piece rows
   const char *zero_line = (const char *)g_zero_page +
-                          ((((blockIdx.x * 29 + blockIdx.y * 7 + wave) * 8 + prow) & 7) * 128 + pchunk * 16) +
-                          (((blockIdx.x * 13 + wave * 5) & 7) * 8192);
+                          ((((blockIdx.x * 29 + blockIdx.y * 7 + sw) * 8 + prow) & 7) * 128 + pchunk * 16) +
+                          (((blockIdx.x * 13 + sw * 5) & 7) * 8192);
   int a_row[PA], w_row[PB];
   const char *a_src[PA];
   const char *w_src[PB];
 #pragma unroll
   for (int j = 0; j < PA; ++j) {
-    const int r = (wave * PA + j) * 8 + prow;  // row inside the BM-row tile
+    const int r = (sw * PA + j) * 8 + prow;  // row inside the BM-row tile
     a_row[j] = min(m0 + r, p.M - 1);           // tail rows re-read the last row (never stored)
     a_src[j] = Ab + (size_t)a_row[j] * p.lda * ES + (pchunk ^ prow) * 16;
   }
 #pragma unroll
   for (int j = 0; j < PB; ++j) {
-    const int r = (wave * PB + j) * 8 + prow;
+    const int r = (sw * PB + j) * 8 + prow;
     w_row[j] = n0 + r;
     w_src[j] = (w_row[j] < p.N) ? Wb + (size_t)w_row[j] * p.ldw * ES + (pchunk ^ prow) * 16
                                 : zero_line + ((j * 5 + 3) & 7) * 1024;
@@ -202,8 +212,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   unsigned st_ldsA = 0, st_ldsB = 0;
   size_t st_koff = 0;
   auto stage_begin = [&](int kt, int buf) {
-    st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
-    st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
+    st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + sw * PA * 1024);
+    st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + sw * PB * 1024);
     st_koff = (size_t)kt * ROW_BYTES;
     if constexpr (GATHER) {
       const int k0 = kt * BK;
@@ -330,7 +340,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   // one row-shaped term goes straight into the accumulator registers (no extra live registers):
   // the residual (proj / fc2) or the pos-embed row bias (patch embed); the column bias is added
   // from TN float4 registers in the epilogue.
-  const float *init_base = (epi & PP_EPI_RESIDUAL) ? Rb : ((epi & PP_EPI_ROWBIAS) ? p.rowbias : nullptr);
+  const float *init_base =
+      is_producer ? nullptr : ((epi & PP_EPI_RESIDUAL) ? Rb : ((epi & PP_EPI_ROWBIAS) ? p.rowbias : nullptr));
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
     bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (epi & PP_EPI_BIAS) {
+    if ((epi & PP_EPI_BIAS) && !is_producer) {
       if constexpr (vec_ok) {
         if (n < p.N) bias4[j] = *reinterpret_cast<const float4 *>(bias + n);
       } else {
@@ -380,12 +391,54 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
   unsigned long long c_wait = 0, c_bar = 0, c_stage = 0, c_comp = 0;
 #endif
   PP_STAMP(t_begin);
+#ifdef PP_GEMM_STAMPS
+  unsigned long long t_pro_v = t_begin;
+#endif
+  if constexpr (NWP > 0) {
+    // ---- wave-specialised K-loop: same barrier protocol, the two halves of each iteration on
+    // different waves.  Every wave executes exactly nkt barriers.
+    if (is_producer) {
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nkt) stage_all(s, s);
+      int buf = 0;
+      for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + STAGES - 1 <= nkt) {
+          wait_vmcnt<(STAGES - 2) * PIECES>();
+        } else {
+          wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nkt) {
+          int nb = buf + STAGES - 1;
+          if (nb >= STAGES) nb -= STAGES;
+          stage_all(kt + STAGES - 1, nb);
+        }
+        if (++buf == STAGES) buf = 0;
+      }
+    } else {
+      int buf = 0;
+      for (int kt = 0; kt < nkt; ++kt) {
+        PP_STAMP(tb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PP_STAMP(tc);
+        compute(buf, std::false_type{});
+        PP_STAMP(te);
+        PP_ACC(c_bar, tb, tc);
+        PP_ACC(c_comp, tc, te);
+        if (++buf == STAGES) buf = 0;
+      }
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nkt) stage_all(s, s);
   // the loads above (bias, row map) are older than every DMA piece: retire them once, here, so that
   // inside the loop only DMA pieces are outstanding and the counted waits are exact
-  PP_STAMP(t_pro);
+#ifdef PP_GEMM_STAMPS
+  t_pro_v = stamp();
+#endif
   int buf = 0, kt = 0;
   // steady state: every iteration prefetches tile kt + STAGES - 1 (one code path in the loop body,
   // so the accumulators stay in place across iterations)
@@ -426,6 +479,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     PP_ACC(c_comp, tc, te);
     if (++buf == STAGES) buf = 0;
   }
+  }
   PP_STAMP(t_loop);
 
   // ---- epilogue.  The W fragment is the MFMA "A" operand and the activation fragment the "B"
@@ -445,6 +499,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
       int *rows_lds = reinterpret_cast<int *>(smem + BM * CS);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        if (is_producer) break;
         const int lr = wm * (BM / WGM) + i * 16 + frow;
         if (wn == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
 #pragma unroll
@@ -468,7 +523,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
       __syncthreads();
       constexpr int CPR = BN * 2 / 16;               // 16-B chunks per row
       const int ncols16 = min(CPR, (p.N - n0) / 8);   // N % 8 == 0 on this path
-      for (int c = tid; c < BM * CPR; c += 64 * NW) {
+      for (int c = tid; c < BM * CPR; c += NTHREADS) {
         const int lr = c / CPR, cc = c - lr * CPR;
         const int r = rows_lds[lr];
         if (r < 0 || cc >= ncols16) continue;
@@ -481,7 +536,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + wm * (BM / WGM) + i * 16 + frow;
-    if (stored || m >= p.M) continue;
+    if (stored || is_producer || m >= p.M) continue;
     const int r = out_row[i];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -534,7 +589,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_kernel(GemmParams p) {
     PP_STAMP(t_end);
     unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
                             ((size_t)blockIdx.x * NW + wave) * 8;
-    o[0] = t_pro - t_begin; o[1] = c_wait; o[2] = c_bar; o[3] = c_stage; o[4] = c_comp;  // stage now inside compute
+    o[0] = t_pro_v - t_begin; o[1] = c_wait; o[2] = c_bar; o[3] = c_stage; o[4] = c_comp;  // stage now inside compute
     o[5] = t_end - t_loop; o[6] = t_end - t_begin; o[7] = t_begin;
   }
 #endif
@@ -593,9 +648,10 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
   // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages),
-  // 5 = 384x128 (8 waves, 2 stages; the N = 256 deconvolution layers).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
+  // 5 = 384x128 (8 waves, 2 stages; the N = 256 deconvolution layers), 6 = 192x192 wave-specialised
+  // (8 consumer + 4 producer waves, 3 stages).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 5, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 6, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -618,7 +674,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : 192);
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : (cfg == 3 ? 192 : 128));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : 128));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   const int rn_ = (cfg >= 3) ? 4 : 8;
@@ -630,19 +686,20 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                        : 0;
   dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
-#define PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_)                                         \
+#define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_)                                   \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
     static thread_local bool attr = false;                                                            \
     if (!attr) {                                                                                      \
       PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
-          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_>),          \
+          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_>),    \
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
       attr = true;                                                                                    \
     }                                                                                                 \
-    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_>), grid,                     \
-                       dim3(64 * WGM_ * WGN_), lds, s, p);                                            \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_>), grid,               \
+                       dim3(64 * (WGM_ * WGN_ + NWP_)), lds, s, p);                                   \
   } while (0)
+#define PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_) PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, 0)
 #define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
   do {                                                                                                \
     if (gather) PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, true, true);                           \
@@ -662,15 +719,20 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 2) PP_LAUNCH_GEMM(bf16_t, 192, 96, 2, 2, 2);
     else if (cfg == 3) PP_LAUNCH_GEMM(bf16_t, 192, 192, 2, 4, 3);
     else if (cfg == 4) PP_LAUNCH_GEMM(bf16_t, 192, 128, 2, 4, 3);
-    else PP_LAUNCH_GEMM(bf16_t, 384, 128, 2, 4, 2);
+    else if (cfg == 5) PP_LAUNCH_GEMM(bf16_t, 384, 128, 2, 4, 2);
+    else if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, true, true, 4);
+    else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
   } else {
     if (cfg == 1) PP_LAUNCH_GEMM(float, 128, 128, 2, 2, 2);
     else if (cfg == 2) PP_LAUNCH_GEMM(float, 192, 96, 2, 2, 2);
     else if (cfg == 3) PP_LAUNCH_GEMM(float, 192, 192, 2, 4, 3);
     else if (cfg == 4) PP_LAUNCH_GEMM(float, 192, 128, 2, 4, 3);
-    else PP_LAUNCH_GEMM(float, 384, 128, 2, 4, 2);
+    else if (cfg == 5) PP_LAUNCH_GEMM(float, 384, 128, 2, 4, 2);
+    else if (gather) PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, true, true, 4);
+    else PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, false, true, 4);
   }
 #undef PP_LAUNCH_GEMM_V
+#undef PP_LAUNCH_GEMM_W
 #undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");
   return 0;
