@@ -233,12 +233,15 @@ def main():
         assert result.shape == (B * world, cfg["K"], 7)
 
         # ---- kernel-level timing with HIP events on the launch stream (eager pass, same inputs)
+        from probpose_pytorch_amd import engine
         prof = []
+        engine.SERIALIZE_HEAD = True      # one stream: per-launch durations are the kernels' own
         ops.set_profile(prof)
         for _ in range(3):
             local_step()
         torch.cuda.synchronize()
         ops.set_profile(None)
+        engine.SERIALIZE_HEAD = False
     agg = {}
     for name, work, s, e, _info in prof:
         a = agg.setdefault(name, [0, 0.0, 0.0])

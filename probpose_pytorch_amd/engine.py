@@ -20,6 +20,10 @@ from .ops import EPI_GELU, EPI_OUT_F32, EPI_RELU
 
 _PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
+# bench.py's kernel-timing pass sets this to run the head's two branches back to back on one stream,
+# so that per-launch event timings are not inflated by the other branch sharing the CUs
+SERIALIZE_HEAD = False
+
 
 def _signature(module: torch.nn.Module):
     sig = []
@@ -262,8 +266,9 @@ class HeadPlan:
         aux = torch.empty((4, B, K), dtype=torch.float32, device=dev)
         heat = torch.empty((B, K, h * 2 ** len(self.deconvs), w * 2 ** len(self.deconvs)), dtype=torch.float32,
                            device=dev)
-        self._aux_stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(self._aux_stream):
+        aux_stream = torch.cuda.current_stream(dev) if SERIALIZE_HEAD else self._aux_stream
+        aux_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(aux_stream):
             a, ah, aw = feats, h, w
             for i, (p, (ro, _, _)) in enumerate(zip(self.pools, tb["aux"])):
                 M = B * ah * aw
@@ -307,7 +312,7 @@ class HeadPlan:
             ops.gemm(x, f["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=f["b"],
                      rowoff=tb["final"], seg_len=cin, heatmap=(K, hh * ww, self.temperature))
         # ---- join the aux-branch stream (forked above)
-        torch.cuda.current_stream(dev).wait_stream(self._aux_stream)
+        torch.cuda.current_stream(dev).wait_stream(aux_stream)
         return (heat, aux[0].reshape(B, K, 1, 1), aux[1].reshape(B, K, 1, 1), aux[2].reshape(B, K, 1, 1),
                 aux[3].reshape(B, K, 1, 1))
 

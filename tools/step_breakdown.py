@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import bench
-from probpose_pytorch_amd import ops
+from probpose_pytorch_amd import engine, ops
+
+engine.SERIALIZE_HEAD = True
 from probpose_pytorch_amd.synthetic import synthetic_crops
 
 cfg = dict(bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "vit_b"])
