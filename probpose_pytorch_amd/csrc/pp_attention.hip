@@ -28,12 +28,22 @@ int attention_valu(const void *qkv, void *out, int B, int N, int heads, int hd, 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int AT_HD = 64;
 constexpr int AT_NMAX = 192;              // keys / queries held on chip
 constexpr int AT_NT = AT_NMAX / 16;       // 12 key tiles
 constexpr int AT_QT = 3;                  // query tiles (16 rows) per wave
-constexpr int AT_KROW = AT_HD * 2;        // 128 B per K / V row in LDS
-constexpr int AT_LDS = 2 * AT_NMAX * AT_KROW;  // K + V, row-major, 48 KiB
+// head_dim 64 (ViT-B/L) or 32 (the reference's own ViT: embed 384 / 12 heads, backbone.py:30)
+template <int HD> struct AttGeom {
+  static constexpr int KROW = HD * 2;                 // bytes per K / V row in LDS (128 or 64)
+  static constexpr int LDS = 2 * AT_NMAX * KROW;      // K + V, row-major
+  static constexpr int CHUNKS = HD / 8;               // 16-B chunks per row
+  static constexpr int KS = HD / 32;                  // 32-deep MFMA steps of the first product
+  static constexpr int DT = HD / 16;                  // 16-dim output tiles
+  static constexpr int RPP = 1024 / KROW;             // rows per 1-KiB DMA piece
+  // 16-B chunk swizzle that makes a 16-row ds_read_b128 column hit 16 distinct bank slots
+  static __device__ __forceinline__ int swz(int row, int chunk) {
+    return HD == 64 ? (chunk ^ (row & 7)) : (chunk ^ ((row >> 2) & 3));
+  }
+};
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (-DPP_ATT_STAMPS): phase cycle counts of wave 0 go behind the output tensor.
@@ -65,12 +75,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
 
+template <int AT_HD>
 __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__restrict__ qkv,
                                                                 bf16_t *__restrict__ out, int N,
                                                                 int heads, float scale_log2e) {
+  using G = AttGeom<AT_HD>;
+  constexpr int AT_KROW = G::KROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *Ks = smem;                          // [192][64] bf16, 16-B chunks XOR-swizzled by (row & 7)
-  char *Vs = smem + AT_NMAX * AT_KROW;      // [192][64] bf16, same layout; read transposed (ds_read_b64_tr_b16)
+  char *Ks = smem;                          // [192][HD] bf16, 16-B chunks XOR-swizzled
+  char *Vs = smem + AT_NMAX * AT_KROW;      // [192][HD] bf16, same layout; read transposed (ds_read_b64_tr_b16)
   const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
   const int C = heads * AT_HD, ld = 3 * C;
   const bf16_t *base = qkv + (size_t)b * N * ld + h * AT_HD;
@@ -84,13 +97,14 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
   // zero line.  V is NOT transposed here: the second product reads it through ds_read_b64_tr_b16.
   {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
-    const int prow = lane >> 3, pchunk = lane & 7;
+    constexpr int PIECES_W = AT_NMAX / G::RPP / 4;       // 1-KiB pieces per wave, for K and for V
+    const int prow = lane / G::CHUNKS, pchunk = lane % G::CHUNKS;
 #pragma unroll
-    for (int j = 0; j < AT_NMAX / 8 / 4; ++j) {          // 6 pieces of 8 rows per wave, for K and for V
-      const int r = (wave * (AT_NMAX / 8 / 4) + j) * 8 + prow;
-      const int lchunk = pchunk ^ (r & 7);
+    for (int j = 0; j < PIECES_W; ++j) {
+      const int r = (wave * PIECES_W + j) * G::RPP + prow;
+      const int lchunk = G::swz(r, pchunk);
       const bf16_t *src = (r < N) ? base + (size_t)r * ld + lchunk * 8 : nullptr;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (wave * (AT_NMAX / 8 / 4) + j) * 1024);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (wave * PIECES_W + j) * 1024);
       att_glds16(src ? (const void *)(src + C) : (const void *)(g_att_zero + lane * 16), dst);
       att_glds16(src ? (const void *)(src + 2 * C) : (const void *)(g_att_zero + lane * 16), dst + AT_NMAX * AT_KROW);
     }
@@ -98,12 +112,12 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
 
   // ---- Q fragments straight from global: B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]
   const int q0 = wave * (AT_QT * 16);
-  uint4 qf[AT_QT][2];
+  uint4 qf[AT_QT][G::KS];
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
     const int q = q0 + t * 16 + lrow;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < G::KS; ++s) {
       qf[t][s] = make_uint4(0, 0, 0, 0);
       if (q < N) qf[t][s] = *reinterpret_cast<const uint4 *>(base + (size_t)q * ld + s * 32 + g * 8);
     }
@@ -119,13 +133,13 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
   // accumulator are rescaled by alpha = exp2((m_old - m_new) * c) between the blocks.
   constexpr int KB_TILES = AT_NT / 2;  // 6 key tiles per block
   float m_run[AT_QT], l_run[AT_QT];
-  f32x4 oacc[4][AT_QT];
+  f32x4 oacc[G::DT][AT_QT];
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
     m_run[t] = -__builtin_inff();
     l_run[t] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < G::DT; ++dt) oacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
@@ -141,8 +155,8 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       for (int t = 0; t < AT_QT; ++t) sacc[kt][t] = init;
       const int r = (kb * KB_TILES + kt) * 16 + lrow;
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint4 kf = *reinterpret_cast<const uint4 *>(Ks + r * AT_KROW + (((4 * s + g) ^ (r & 7)) << 4));
+      for (int s = 0; s < G::KS; ++s) {
+        const uint4 kf = *reinterpret_cast<const uint4 *>(Ks + r * AT_KROW + (G::swz(r, 4 * s + g) << 4));
 #pragma unroll
         for (int t = 0; t < AT_QT; ++t)
           sacc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&kf),
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       l_run[t] = l_run[t] * alpha + l;
       m_run[t] = m_new;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < G::DT; ++dt) {
         oacc[dt][t][0] *= alpha; oacc[dt][t][1] *= alpha; oacc[dt][t][2] *= alpha; oacc[dt][t][3] *= alpha;
       }
     }
@@ -192,7 +206,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
         pf[t].w = pack_bf16x2(sacc[2 * u + 1][t][2], sacc[2 * u + 1][t][3]);
       }
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < G::DT; ++dt) {
         // A operand = V^T fragment: lane (dim = lrow, g) needs keys {4g..4g+3} and {16+4g..16+4g+3}
         // of this 32-key step for its dim.  Each 16-lane group g issues one transposing read per key
         // quartet: lane 4q+p of the group addresses row (key) q, dims 4p..4p+3 of the 16-dim block;
@@ -200,9 +214,9 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
         const int tq = lrow >> 2, tp = lrow & 3;
         const int key0 = kb * (KB_TILES * 16) + 32 * u + 4 * g + tq;
         const int ch = 2 * dt + (tp >> 1);
-        const int a0 = key0 * AT_KROW + ((ch ^ (key0 & 7)) << 4) + (tp & 1) * 8;
+        const int a0 = key0 * AT_KROW + (G::swz(key0, ch) << 4) + (tp & 1) * 8;
         const int key1 = key0 + 16;
-        const int a1 = key1 * AT_KROW + ((ch ^ (key1 & 7)) << 4) + (tp & 1) * 8;
+        const int a1 = key1 * AT_KROW + (G::swz(key1, ch) << 4) + (tp & 1) * 8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4 *)(Vs + a0));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
     if (q >= N) continue;
     bf16_t *orow = out + ((size_t)b * N + q) * C + h * AT_HD;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
+    for (int dt = 0; dt < G::DT; ++dt) {
       uint2 pk;
       pk.x = pack_bf16x2(oacc[dt][t][0] * inv_l[t], oacc[dt][t][1] * inv_l[t]);
       pk.y = pack_bf16x2(oacc[dt][t][2] * inv_l[t], oacc[dt][t][3] * inv_l[t]);
@@ -265,10 +279,14 @@ extern "C" int pp_attention(const void *qkv, void *out, int B, int N, int heads,
   PP_REQUIRE(qkv && out, "pp_attention: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == PP_BF16) {
-    if (hd == AT_HD && N <= AT_NMAX && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0) {
+    if ((hd == 64 || hd == 32) && N <= AT_NMAX && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0) {
       const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
-      hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * heads), dim3(256), AT_LDS, s, (const bf16_t *)qkv,
-                         (bf16_t *)out, N, heads, scale_log2e);
+      if (hd == 64)
+        hipLaunchKernelGGL(attention_mfma_kernel<64>, dim3(B * heads), dim3(256), AttGeom<64>::LDS, s,
+                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e);
+      else
+        hipLaunchKernelGGL(attention_mfma_kernel<32>, dim3(B * heads), dim3(256), AttGeom<32>::LDS, s,
+                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e);
       PP_CHECK_LAUNCH("attention_mfma_kernel");
       return 0;
     }
