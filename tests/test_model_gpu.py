@@ -137,3 +137,20 @@ def test_model_rebuilds_plan_when_weights_change(pkg):
     with pytest.raises(RuntimeError):
         m.head.train()
         m(x)
+
+
+def test_inference_cli_end_to_end(pkg, tmp_path, capsys):
+    """The reference CLI's call sequence (inference.py:61-112) on a synthetic crop, fp32 parity mode,
+    against the oracle with the same weights."""
+    from probpose_pytorch_amd import inference
+    preds = inference.main(["--backbone", "vit_s", "--input_size", "192,256", "--output", str(tmp_path)])
+    assert (tmp_path / "heatmap_16.npy").exists()
+    sd = pkg["syn"].synthetic_model_state((256, 192), 16, 384, 12, 17, 3, (256, 256), seed=0)
+    x = pkg["syn"].synthetic_crops(1, 256, 192, seed=1234)
+    with torch.no_grad():
+        want = orc.model_forward(sd, x, patch=16, heads=12, pools=inference.default_pools((16, 12)))
+    ref = orc.codec_decode([w.numpy() for w in want], (192, 256), (48, 64), np.array([0.05] * 17))
+    assert preds[0][0].shape == (1, 17, 2)
+    for a, b in zip(preds[1:], ref[1:]):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
+    assert "Predictions:" in capsys.readouterr().out

@@ -98,3 +98,22 @@ def test_drop_in_import_paths():
     from probpose.model import ProbPoseModel  # noqa: F401
     from probpose.util import to_numpy  # noqa: F401
     assert probpose.codec is probpose_pytorch_amd.codec
+
+
+def test_inference_harness_host_logic(tmp_path):
+    """Counterpart of the reference CLI (inference.py:61-112): model construction for an input size,
+    safe checkpoint loading, pool schedule that always ends at 1x1."""
+    from probpose_pytorch_amd import inference
+    for grid in [(16, 12), (24, 18), (24, 24), (8, 8)]:
+        h, w = grid
+        for p in inference.default_pools(grid):
+            h, w = h // p[0], w // p[1]
+        assert (h, w) == (1, 1)
+    model, hm_size = inference.build_model((192, 256), 17, "vit_s")
+    assert hm_size == (48, 64) and model.backbone.model.embed_dim == 384
+    torch.save(model.state_dict(), tmp_path / "full.pt")
+    res = inference.load_weights(model, tmp_path / "full.pt", "full")
+    assert not res.missing_keys
+    torch.save(model, tmp_path / "pickled_module.pt")           # the reference's torch.save(model) style
+    with pytest.raises(RuntimeError, match="state_dict"):
+        inference.load_weights(model, tmp_path / "pickled_module.pt", "full")
