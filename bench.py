@@ -176,6 +176,7 @@ def main():
     B = cfg["batch"]
     H, W = cfg["img"]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    ops.AUTOTUNE = True     # per-shape tile selection measured on this device during the warm-up
     model, codec, sd = build(cfg, dtype, device)
     x = synthetic_crops(B, H, W, seed=1234 + rank).to(device)       # resident in HBM before timing
 
@@ -259,6 +260,7 @@ def main():
         d_n, d_bytes, d_t = per_step.get("decode", (0, 0.0, 1.0))
         a_n, a_flops, a_t = per_step.get("attention", (0, 0.0, 1.0))
         g_traffic, d_traffic, traffic_src = pmc_traffic() if args.config == "vit_b" and B == 64 else (None, None, None)
+        tiles = {f"M{k[0]}xN{k[1]}xK{k[2]}" + (f"x{k[3]}" if k[3] > 1 else ""): v for k, v in ops._TUNE_CACHE.items()}
         line = {
             "metric": "person_crops_per_sec", "value": round(crops_per_s, 2), "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -280,6 +282,7 @@ def main():
                                 "bytes_per_launch": d_bytes},
             "attention": {"achieved_tflops": round(a_flops / a_t / 1e12, 2), "ms_per_step": round(a_t * 1e3, 3)},
             "kernel_ms_per_step": {k: round(v[2] * 1e3, 3) for k, v in per_step.items()},
+            "gemm_tiles_autotuned": tiles,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)

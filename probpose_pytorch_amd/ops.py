@@ -48,6 +48,42 @@ def _p(t):
     return _lib.ptr(t)
 
 
+# Tile autotuning ("measure, don't guess"): the best output-tile configuration of pp_gemm depends on the
+# shape (tile quantisation against 256 CUs, K length, epilogue) and varies by several percent between
+# devices.  With AUTOTUNE on, the first call of every distinct GEMM signature times the candidate
+# configurations on scratch outputs (HIP events, outside any graph capture) and caches the winner.
+AUTOTUNE = False
+_TUNE_CACHE: dict = {}
+_TUNE_CANDIDATES = (2, 3, 4, 5)
+
+
+def _tune(a, key, out, residual):
+    L = _lib.lib()
+    stream = _lib.stream_ptr()
+    scratch = torch.empty_like(out)
+    c_saved, r_saved = a.C, a.residual
+    a.C = _p(scratch)
+    if residual is not None:
+        a.residual = _p(scratch)
+    best, best_t = 0, float("inf")
+    for cand in _TUNE_CANDIDATES:
+        a.tile = cand
+        if L.pp_gemm(C.byref(a), stream) != 0:      # configuration not applicable to this problem
+            continue
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(3):
+            L.pp_gemm(C.byref(a), stream)
+        e.record()
+        e.synchronize()
+        t = s.elapsed_time(e)
+        if t < best_t:
+            best, best_t = cand, t
+    a.C, a.residual = c_saved, r_saved
+    _TUNE_CACHE[key] = best
+    return best
+
+
 def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
          strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0):
@@ -72,6 +108,13 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         a.hm_K, a.hm_HW, a.hm_temperature = heatmap
     a.epilogue = epilogue
     a.tile = tile
+    if tile == 0 and AUTOTUNE and M * N * Kd >= (1 << 24):
+        key = (M, N, Kd, batch, a.dtype, rowoff is not None, out_rowmap is not None, epilogue, lda, ldw, ldc)
+        best = _TUNE_CACHE.get(key)
+        if best is None and not torch.cuda.is_current_stream_capturing():
+            best = _tune(a, key, out, residual)
+        if best:
+            a.tile = best
     rc = _timed("gemm", 2.0 * M * N * Kd * batch, lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()),
                 f"M={M} N={N} K={Kd} batch={batch} gather={rowoff is not None} epi={epilogue}")
     _lib.check(rc, "pp_gemm")
