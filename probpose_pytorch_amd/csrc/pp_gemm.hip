@@ -492,43 +492,52 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     // bf16 outputs: stage the C tile through LDS (the K-loop buffers are dead) and store whole rows,
     // 16 B per lane and BN*2 contiguous bytes per row, instead of 8-B pieces of 16 different rows
     // per wave-instruction (the direct path's store tail cost ~24 % of a K = 768 tile).
-    constexpr int CS = BN * 2 + 16;                 // padded row stride: keeps 16-B alignment, spreads banks
+    // Tiles wider than the staging buffers can hold go through in NPASS column passes.
+    constexpr int NPASS = (BM * (BN * 2 + 16) + BM * 4 <= STAGES * STAGE_BYTES) ? 1 : 2;
+    constexpr int PBN = BN / NPASS;                  // columns per pass
+    constexpr int CS = PBN * 2 + 16;                 // padded row stride: keeps 16-B alignment, spreads banks
     static_assert(BM * CS + BM * 4 <= STAGES * STAGE_BYTES, "C tile must fit the staging buffers");
+    static_assert(WGN % NPASS == 0, "column passes must split the wave grid");
     if (p.lds_epilogue) {
-      __syncthreads();                               // every wave is done reading the last K-tile
       int *rows_lds = reinterpret_cast<int *>(smem + BM * CS);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (is_producer) break;
-        const int lr = wm * (BM / WGM) + i * 16 + frow;
-        if (wn == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
+      for (int pass = 0; pass < NPASS; ++pass) {
+        __syncthreads();                             // K-loop reads (pass 0) / previous pass's row stores done
+        const bool mine = !is_producer && (wn / (WGN / NPASS)) == pass;
+        const int wn_in = wn - pass * (WGN / NPASS);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
-                        acc[i][j][3] + bias4[j].w};
-          if (epi & PP_EPI_GELU) {
+        for (int i = 0; i < TM; ++i) {
+          if (!mine) break;
+          const int lr = wm * (BM / WGM) + i * 16 + frow;
+          if (wn_in == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+          for (int j = 0; j < TN; ++j) {
+            float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                          acc[i][j][3] + bias4[j].w};
+            if (epi & PP_EPI_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+            }
+            if (epi & PP_EPI_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2 *>(smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * 2) = pk;
           }
-          if (epi & PP_EPI_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          uint2 pk;
-          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-          *reinterpret_cast<uint2 *>(smem + lr * CS + (wn * (BN / WGN) + j * 16 + fq * 4) * 2) = pk;
         }
-      }
-      __syncthreads();
-      constexpr int CPR = BN * 2 / 16;               // 16-B chunks per row
-      const int ncols16 = min(CPR, (p.N - n0) / 8);   // N % 8 == 0 on this path
-      for (int c = tid; c < BM * CPR; c += NTHREADS) {
-        const int lr = c / CPR, cc = c - lr * CPR;
-        const int r = rows_lds[lr];
-        if (r < 0 || cc >= ncols16) continue;
-        const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
-        *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(Cb) + (size_t)r * p.ldc + n0 + cc * 8) = v;
+        __syncthreads();
+        constexpr int CPR = PBN * 2 / 16;             // 16-B chunks per row
+        const int ncols16 = max(0, min(CPR, (p.N - n0 - pass * PBN) / 8));   // N % 8 == 0 on this path
+        for (int c = tid; c < BM * CPR; c += NTHREADS) {
+          const int lr = c / CPR, cc = c - lr * CPR;
+          const int r = rows_lds[lr];
+          if (r < 0 || cc >= ncols16) continue;
+          const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
+          *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(Cb) + (size_t)r * p.ldc + n0 + pass * PBN + cc * 8) = v;
+        }
       }
       stored = true;
     }
@@ -649,9 +658,9 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
   // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages),
   // 5 = 384x128 (8 waves, 2 stages; the N = 256 deconvolution layers), 6 = 192x192 wave-specialised
-  // (8 consumer + 4 producer waves, 3 stages).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
+  // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 6, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 7, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -674,7 +683,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : 192);
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : 128));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : (cfg == 7 ? 384 : 128)));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   const int rn_ = (cfg >= 3) ? 4 : 8;
@@ -720,6 +729,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 3) PP_LAUNCH_GEMM(bf16_t, 192, 192, 2, 4, 3);
     else if (cfg == 4) PP_LAUNCH_GEMM(bf16_t, 192, 128, 2, 4, 3);
     else if (cfg == 5) PP_LAUNCH_GEMM(bf16_t, 384, 128, 2, 4, 2);
+    else if (cfg == 7) PP_LAUNCH_GEMM(bf16_t, 192, 384, 2, 4, 2);
     else if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
   } else {
@@ -728,6 +738,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 3) PP_LAUNCH_GEMM(float, 192, 192, 2, 4, 3);
     else if (cfg == 4) PP_LAUNCH_GEMM(float, 192, 128, 2, 4, 3);
     else if (cfg == 5) PP_LAUNCH_GEMM(float, 384, 128, 2, 4, 2);
+    else if (cfg == 7) PP_LAUNCH_GEMM(float, 192, 384, 2, 4, 2);
     else if (gather) PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, false, true, 4);
   }

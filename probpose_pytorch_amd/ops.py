@@ -54,7 +54,7 @@ def _p(t):
 # configurations on scratch outputs (HIP events, outside any graph capture) and caches the winner.
 AUTOTUNE = False
 _TUNE_CACHE: dict = {}
-_TUNE_CANDIDATES = (2, 3, 4, 5)
+_TUNE_CANDIDATES = (2, 3, 4, 5, 7)
 
 
 def _tune(a, key, out, residual):

@@ -36,7 +36,7 @@ def _tol(dtype, out_dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 768, 768), (300, 200, 128), (1, 17, 256), (257, 129, 64),
                                    (384, 2304, 768), (192, 96, 64), (193, 97, 128), (400, 400, 3072)])
 def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
@@ -78,7 +78,7 @@ def test_gemm_exact_integer_data_catches_layout_bugs(ops, dtype):
     g = torch.Generator().manual_seed(0)
     A = torch.randint(-3, 4, (M, K), generator=g).to(dtype).cuda()
     W = torch.randint(-3, 4, (N, K), generator=g).to(dtype).cuda()
-    for tile in (0, 1, 2, 3, 4, 5, 6):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7):
         out = ops.linear(A, W, out_dtype=torch.float32, tile=tile)
         assert torch.equal(out.double(), A.double() @ W.double().t())
     # auto-selection picks the 192x96 tile when it saves a round of workgroups (M = 16 crops x 192)
@@ -98,7 +98,7 @@ def test_gemm_conv3x3_gather_batched_branches(ops, dtype):
     Wp = torch.stack([pack.conv_taps_major(wt[i].cpu()) for i in range(4)]).to(dtype).cuda()
     ro = pack.conv_gather_table(B, h, w, 3, 3, 1, 1, 4 * C).cuda()
     out = torch.empty((B * h * w, 4 * C), dtype=dtype, device="cuda")
-    for tile in (1, 2, 3, 4, 5, 6):
+    for tile in (1, 2, 3, 4, 5, 6, 7):
         out.zero_()
         ops.gemm(x, Wp, out, M=B * h * w, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C, bias=bias, rowoff=ro,
                  seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C, strideBias=C, tile=tile)
@@ -114,7 +114,7 @@ def _check_branches(x, Wp, bias, out, B, h, w, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("k", [4, 3, 2])
 def test_gemm_deconv_parities_scatter(ops, dtype, k, tile):
     from probpose_pytorch_amd import pack
