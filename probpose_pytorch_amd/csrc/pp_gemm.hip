@@ -488,17 +488,18 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
   // All additive terms are already in the accumulators: activation, convert, store.
   char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
   bool stored = false;
-  if constexpr (sizeof(T) == 2 && VEC) {
-    // bf16 outputs: stage the C tile through LDS (the K-loop buffers are dead) and store whole rows,
-    // 16 B per lane and BN*2 contiguous bytes per row, instead of 8-B pieces of 16 different rows
-    // per wave-instruction (the direct path's store tail cost ~24 % of a K = 768 tile).
-    // Tiles wider than the staging buffers can hold go through in NPASS column passes.
-    constexpr int NPASS = (BM * (BN * 2 + 16) + BM * 4 <= STAGES * STAGE_BYTES) ? 1 : 2;
-    constexpr int PBN = BN / NPASS;                  // columns per pass
-    constexpr int CS = PBN * 2 + 16;                 // padded row stride: keeps 16-B alignment, spreads banks
-    static_assert(BM * CS + BM * 4 <= STAGES * STAGE_BYTES, "C tile must fit the staging buffers");
-    static_assert(WGN % NPASS == 0, "column passes must split the wave grid");
-    if (p.lds_epilogue) {
+  if constexpr (VEC) {
+    // Stage the C tile through LDS (the K-loop buffers are dead) and store whole rows: 16 B per lane
+    // and PBN*OES contiguous bytes per row instead of 8/16-B pieces of 16 different rows per
+    // wave-instruction (the direct path's store tail cost ~24 % of a K = 768 tile).  Tiles wider than
+    // the staging buffers go through in NPASS column passes.  OES = output element size.
+    auto lds_epilogue = [&]<int OES>(std::integral_constant<int, OES>) {
+      constexpr int BUDGET = STAGES * STAGE_BYTES;
+      constexpr auto fits = [](int np) { return BM * (BN / np * OES + 16) + BM * 4 <= BUDGET && WGN % np == 0; };
+      constexpr int NPASS = fits(1) ? 1 : (fits(2) ? 2 : 4);
+      static_assert(fits(NPASS), "C tile must fit the staging buffers");
+      constexpr int PBN = BN / NPASS;                  // columns per pass
+      constexpr int CS = PBN * OES + 16;               // padded row stride: keeps 16-B alignment, spreads banks
       int *rows_lds = reinterpret_cast<int *>(smem + BM * CS);
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
@@ -516,29 +517,40 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
                           acc[i][j][3] + bias4[j].w};
             if (epi & PP_EPI_GELU) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_fast(v[e]);
+              for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
             }
             if (epi & PP_EPI_RELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2 *>(smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * 2) = pk;
+            char *dst = smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * OES;
+            if constexpr (OES == 4) {
+              *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              uint2 pk;
+              pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+              pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              *reinterpret_cast<uint2 *>(dst) = pk;
+            }
           }
         }
         __syncthreads();
-        constexpr int CPR = PBN * 2 / 16;             // 16-B chunks per row
-        const int ncols16 = max(0, min(CPR, (p.N - n0 - pass * PBN) / 8));   // N % 8 == 0 on this path
+        constexpr int CPR = PBN * OES / 16;           // 16-B chunks per row
+        const int ncols16 = max(0, min(CPR, (p.N - n0 - pass * PBN) * OES / 16));
         for (int c = tid; c < BM * CPR; c += NTHREADS) {
           const int lr = c / CPR, cc = c - lr * CPR;
           const int r = rows_lds[lr];
           if (r < 0 || cc >= ncols16) continue;
           const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
-          *reinterpret_cast<uint4 *>(reinterpret_cast<bf16_t *>(Cb) + (size_t)r * p.ldc + n0 + pass * PBN + cc * 8) = v;
+          *reinterpret_cast<uint4 *>(Cb + ((size_t)r * p.ldc + n0 + pass * PBN) * OES + cc * 16) = v;
         }
       }
+    };
+    if (p.lds_epilogue) {
+      if (sizeof(T) == 4 || (epi & PP_EPI_OUT_F32))
+        lds_epilogue(std::integral_constant<int, 4>{});
+      else
+        lds_epilogue(std::integral_constant<int, 2>{});
       stored = true;
     }
   }
@@ -689,10 +701,13 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   const int rn_ = (cfg >= 3) ? 4 : 8;
   const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
   p.blocked = nblk >= 16 ? 1 : 0;
-  p.lds_epilogue = (a->dtype == PP_BF16 && !(a->epilogue & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) && a->N % 8 == 0 &&
-                    a->ldc % 8 == 0 && ((uintptr_t)a->C & 15) == 0 && (a->strideC % 8) == 0)
-                       ? 1
-                       : 0;
+  {
+    const int oes = (a->dtype == PP_F32 || (a->epilogue & PP_EPI_OUT_F32)) ? 4 : 2, per16 = 16 / oes;
+    p.lds_epilogue = (vec && a->N % per16 == 0 && a->ldc % per16 == 0 && ((uintptr_t)a->C & 15) == 0 &&
+                      (a->strideC % per16) == 0)
+                         ? 1
+                         : 0;
+  }
   dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
 #define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_)                                   \
