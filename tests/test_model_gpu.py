@@ -84,7 +84,8 @@ def test_head_fp32_matches_reference_golden(pkg):
 @pytest.mark.parametrize("cfg", [
     dict(img=(64, 48), C=128, depth=2, heads=2, K=17, pools=[(4, 3)], deconv=(64, 64), B=3),
     dict(img=(256, 192), C=384, depth=12, heads=12, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256), B=1),
-], ids=["tiny", "S1-vit-s-256x192"])
+    dict(img=(256, 192), C=768, depth=12, heads=12, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256), B=2),
+], ids=["tiny", "S1-vit-s-256x192", "vit-b-256x192"])
 def test_model_fp32_matches_cpu_oracle(pkg, cfg):
     m, sd = _build(pkg, cfg["img"], cfg["C"], cfg["depth"], cfg["heads"], cfg["K"], cfg["pools"], cfg["deconv"])
     x = pkg["syn"].synthetic_crops(cfg["B"], *cfg["img"], seed=1234)

@@ -19,17 +19,20 @@ L.pp_gemm.argtypes = [C.POINTER(_lib.GemmArgs), C.c_void_p]
 L.pp_last_error.restype = C.c_char_p
 
 M, N, K, tile = (int(v) for v in sys.argv[1:5])
+RESID = len(sys.argv) > 5 and sys.argv[5] == "resid"
 g = torch.Generator().manual_seed(0)
 A = torch.randn((M, K), generator=g).to(torch.bfloat16).cuda()
 W = (torch.randn((N, K), generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
 b = torch.randn((N,), generator=g).cuda()
-out = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+out = torch.randn((M, N), device="cuda") if RESID else torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
 stamps = torch.zeros((1 << 16, 8, 8), dtype=torch.int64, device="cuda")
 a = _lib.GemmArgs()
 a.A, a.W, a.C, a.bias = A.data_ptr(), W.data_ptr(), out.data_ptr(), b.data_ptr()
 a.rowbias = stamps.data_ptr()
 a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
-a.batch, a.dtype, a.epilogue, a.tile = 1, 1, 1 | (1 << 30), tile
+a.batch, a.dtype, a.epilogue, a.tile = 1, 1, (1 | 8 | 16 if RESID else 1) | (1 << 30), tile
+if RESID:
+    a.residual = out.data_ptr()
 for _ in range(3):
     rc = L.pp_gemm(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, L.pp_last_error()
