@@ -118,91 +118,147 @@ __device__ __forceinline__ void finalize(int map, int B, int K, int H, int W, in
 }
 
 // ---------------------------------------------------------------------------
-// LDS-resident path: 12 B of LDS per pixel (f32 map, then reused for the f32
-// convolved map; f64 row-pass intermediate).
+// LDS-resident path: 8 B (f64 row-pass intermediate) + 4 B (f32 map with a reflected 12-column halo,
+// later reused for the f32 convolved map) of LDS per pixel.
 // ---------------------------------------------------------------------------
 constexpr int DEC_THREADS = 256;
+
+// Diagnostic build only (-DPP_DEC_STAMPS): wave-0 phase cycle counts are written through out_conv.
+#ifdef PP_DEC_STAMPS
+__device__ __forceinline__ unsigned long long dec_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define DEC_STAMP(v) const unsigned long long v = dec_stamp()
+#else
+#define DEC_STAMP(v)
+#endif
 
 // Row pass + column pass for a compile-time radius R.  Each thread produces 4 adjacent outputs per
 // item from one shared window of 4 + 2R inputs (3.5x fewer LDS reads than one output per thread at
 // R = 9) with 4 independent float64 FMA chains; per output the taps are still accumulated in
 // ascending order, so the result does not depend on the blocking.
+constexpr int DEC_HALO = 12;  // reflected halo columns on each side of a row in LDS: 4 * ceil(9 / 4)
+
+// Row pass + column pass for a compile-time radius R.  Each thread produces 4 adjacent outputs per
+// item from one shared window of 4 + 2R inputs with 4 independent float64 FMA chains; per output the
+// taps are accumulated in ascending order, so the result does not depend on the blocking.
+// The raw map sits in LDS with a reflected halo (rawp, row stride WP), so every row window is read
+// with 16-B aligned, lane-consecutive ds_read_b128: the stride-4 scalar reads this replaces were an
+// 8-way LDS bank conflict and made the row pass LDS-bound.
 template <int R>
-__device__ __forceinline__ void conv_passes(float *__restrict__ buf, double *__restrict__ tmp, int H,
-                                            int W, const double *__restrict__ wk,
-                                            float *__restrict__ out_conv_map, float &best_v,
-                                            int &best_i, bool &have) {
+__device__ __forceinline__ void conv_passes(const float *__restrict__ rawp, int WP, float *__restrict__ buf,
+                                            double *__restrict__ tmp, int H, int W,
+                                            const double (&wk)[PP_MAX_TAPS], float *__restrict__ out_conv_map,
+                                            float &best_v, int &best_i, bool &have,
+                                            unsigned long long *dbg = nullptr) {
   constexpr int T = 2 * R + 1, WIN = T + 3;
+  constexpr int CR = (R + 3) / 4, NCH = 2 * CR + 1, SKIP = 4 * CR - R;  // aligned chunks around the window
   const int tid = threadIdx.x;
   double w[T];
 #pragma unroll
   for (int j = 0; j < T; ++j) w[j] = wk[j];  // block-uniform -> scalar registers
 
+  // one division per thread up front, then (row, column-group) advances incrementally by DEC_THREADS items
   const int W4 = (W + 3) >> 2;
-  for (int item = tid; item < H * W4; item += DEC_THREADS) {
-    const int y = item / W4, x0 = (item - y * W4) * 4;
-    const float *row = buf + y * W;
-    double v[WIN];
-    if (x0 >= R && x0 + 3 + R < W) {
+  const int step_y = DEC_THREADS / W4, step_x = DEC_THREADS - step_y * W4;
+  {
+    int y = tid / W4, xg = tid - y * W4;
+    for (; y < H;) {
+      const int x0 = xg * 4;
+      const float4 *rp = reinterpret_cast<const float4 *>(rawp + y * WP + x0 + DEC_HALO - 4 * CR);
+      float c[NCH * 4];
 #pragma unroll
-      for (int j = 0; j < WIN; ++j) v[j] = (double)row[x0 - R + j];
-    } else if (W >= R + 3) {   // one reflection suffices (offsets reach at most R + 3 past an edge)
+      for (int q = 0; q < NCH; ++q) {
+        const float4 t = rp[q];
+        c[4 * q + 0] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
+      }
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-      for (int j = 0; j < WIN; ++j) v[j] = (double)row[reflect_once(min(x0 - R + j, 2 * W - 1), W)];
-    } else {
-#pragma unroll
-      for (int j = 0; j < WIN; ++j) v[j] = (double)row[reflect_idx(x0 - R + j, W)];
+      for (int j = 0; j < T; ++j) {
+        a0 = fma(w[j], (double)c[SKIP + j], a0);
+        a1 = fma(w[j], (double)c[SKIP + j + 1], a1);
+        a2 = fma(w[j], (double)c[SKIP + j + 2], a2);
+        a3 = fma(w[j], (double)c[SKIP + j + 3], a3);
+        // keep the four chains interleaved: hipcc otherwise runs them one after another and every
+        // v_fmac_f64 then waits out the previous one's latency (3-4 waves per SIMD cannot hide it)
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      }
+      double *o = tmp + y * W + x0;
+      if (x0 + 3 < W) {
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+      } else {
+        o[0] = a0;
+        if (x0 + 1 < W) o[1] = a1;
+        if (x0 + 2 < W) o[2] = a2;
+      }
+      y += step_y;
+      xg += step_x;
+      if (xg >= W4) {
+        xg -= W4;
+        ++y;
+      }
     }
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-      a0 = fma(w[j], v[j], a0);
-      a1 = fma(w[j], v[j + 1], a1);
-      a2 = fma(w[j], v[j + 2], a2);
-      a3 = fma(w[j], v[j + 3], a3);
-    }
-    double *o = tmp + y * W + x0;
-    o[0] = a0;
-    if (x0 + 1 < W) o[1] = a1;
-    if (x0 + 2 < W) o[2] = a2;
-    if (x0 + 3 < W) o[3] = a3;
   }
+#ifdef PP_DEC_STAMPS
+  if (dbg) dbg[0] = dec_stamp();
+#endif
   __syncthreads();
+#ifdef PP_DEC_STAMPS
+  if (dbg) dbg[1] = dec_stamp();
+#endif
 
   const int H4 = (H + 3) >> 2;
-  for (int item = tid; item < H4 * W; item += DEC_THREADS) {
-    const int y4 = item / W, x = item - y4 * W, y0 = y4 * 4;
-    double v[WIN];
-    if (y0 >= R && y0 + 3 + R < H) {
+  const int cstep_y = DEC_THREADS / W, cstep_x = DEC_THREADS - cstep_y * W;
+  const bool one_reflection_y = H >= R + 3;
+  {
+    int y4 = tid / W, x = tid - y4 * W;
+    for (; y4 < H4;) {
+      const int y0 = y4 * 4;
+      double v[WIN];
+      if (y0 >= R && y0 + 3 + R < H) {
 #pragma unroll
-      for (int j = 0; j < WIN; ++j) v[j] = tmp[(y0 - R + j) * W + x];
-    } else if (H >= R + 3) {
+        for (int j = 0; j < WIN; ++j) v[j] = tmp[(y0 - R + j) * W + x];
+      } else if (one_reflection_y) {
 #pragma unroll
-      for (int j = 0; j < WIN; ++j) v[j] = tmp[reflect_once(min(y0 - R + j, 2 * H - 1), H) * W + x];
-    } else {
+        for (int j = 0; j < WIN; ++j) v[j] = tmp[reflect_once(min(y0 - R + j, 2 * H - 1), H) * W + x];
+      } else {
 #pragma unroll
-      for (int j = 0; j < WIN; ++j) v[j] = tmp[reflect_idx(y0 - R + j, H) * W + x];
-    }
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WIN; ++j) v[j] = tmp[reflect_idx(y0 - R + j, H) * W + x];
+      }
+      double a[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-      a[0] = fma(w[j], v[j], a[0]);
-      a[1] = fma(w[j], v[j + 1], a[1]);
-      a[2] = fma(w[j], v[j + 2], a[2]);
-      a[3] = fma(w[j], v[j + 3], a[3]);
-    }
+      for (int j = 0; j < T; ++j) {
+        a[0] = fma(w[j], v[j], a[0]);
+        a[1] = fma(w[j], v[j + 1], a[1]);
+        a[2] = fma(w[j], v[j + 2], a[2]);
+        a[3] = fma(w[j], v[j + 3], a[3]);
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (y0 + i < H) {
-        const int p = (y0 + i) * W + x;
-        const float cv = (float)a[i];
-        buf[p] = cv;  // the raw copy is dead after the row pass
-        if (out_conv_map) out_conv_map[p] = cv;
-        if (!have || better(cv, p, best_v, best_i)) {
-          best_v = cv;
-          best_i = p;
-          have = true;
+      for (int i = 0; i < 4; ++i) {
+        if (y0 + i < H) {
+          const int p = (y0 + i) * W + x;
+          const float cv = (float)a[i];
+          buf[p] = cv;  // the raw copy is dead after the row pass
+          if (out_conv_map) out_conv_map[p] = cv;
+          // rows ascend, so within a thread a later pixel always has the larger flat index: a strict
+          // '>' keeps the first maximum; NaN handling stays in better()
+          if (!have || better(cv, p, best_v, best_i)) {
+            best_v = cv;
+            best_i = p;
+            have = true;
+          }
         }
+      }
+      y4 += cstep_y;
+      x += cstep_x;
+      if (x >= W) {
+        x -= W;
+        ++y4;
       }
     }
   }
@@ -215,8 +271,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
     DecodeOut o, float *__restrict__ out_conv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = H * W;
-  double *tmp = reinterpret_cast<double *>(smem);               // [HW] f64
-  float *buf = reinterpret_cast<float *>(smem + (size_t)HW * 8);  // [HW] f32: raw, then conv
+  const int WP = 4 * ((W + 3) >> 2) + 2 * DEC_HALO;              // padded row: [halo | W (+pad to 4) | halo]
+  double *tmp = reinterpret_cast<double *>(smem);               // [HW] f64 row-pass result
+  float *rawp = reinterpret_cast<float *>(smem + (size_t)HW * 8);  // [H][WP] f32 raw map + reflected halo
+  float *buf = rawp;                                             // [HW] f32 convolved map (raw is dead by then)
   __shared__ Best red[DEC_THREADS / 64];
 
   const int map = blockIdx.x;
@@ -224,17 +282,45 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
   const float *__restrict__ src = heatmaps + (size_t)map * HW;
   const int tid = threadIdx.x;
 
-  // 1. HBM -> LDS, 16 B per lane when the map allows it
-  if ((HW & 3) == 0) {
-    const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 *d4 = reinterpret_cast<float4 *>(buf);
-    for (int p = tid; p < (HW >> 2); p += DEC_THREADS) d4[p] = s4[p];
-  } else {
-    for (int p = tid; p < HW; p += DEC_THREADS) buf[p] = src[p];
-  }
+  DEC_STAMP(t0);
+  // taps and radius are block-uniform: scalar loads issued now, their latency hides under the map load
   const int r = __builtin_amdgcn_readfirstlane(radius[k]);
-  const double *wk = taps + k * PP_MAX_TAPS;
+  double wk[PP_MAX_TAPS];
+#pragma unroll
+  for (int j = 0; j < PP_MAX_TAPS; ++j) wk[j] = taps[k * PP_MAX_TAPS + j];
+  // 1. HBM -> LDS.  Interior: 16 B per lane when rows are 16-B aligned; halo cells: scipy 'reflect'
+  // of the same rows (their cache lines are already on the way).
+  if ((W & 3) == 0) {
+    const int W4 = W >> 2;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    const int sy = DEC_THREADS / W4, sx = DEC_THREADS - sy * W4;
+    int y = tid / W4, xq = tid - y * W4;
+    for (int p = tid; p < H * W4; p += DEC_THREADS) {
+      *reinterpret_cast<float4 *>(rawp + y * WP + DEC_HALO + 4 * xq) = s4[p];
+      y += sy;
+      xq += sx;
+      if (xq >= W4) {
+        xq -= W4;
+        ++y;
+      }
+    }
+  } else {
+    for (int p = tid; p < HW; p += DEC_THREADS) {
+      const int y = p / W, x = p - y * W;
+      rawp[y * WP + DEC_HALO + x] = src[p];
+    }
+  }
+  {
+    const int npad = WP - W;  // halo + alignment cells per row, 24..27: one 32-lane group per row
+    const int q = tid & 31;
+    if (q < npad) {
+      const int col = q < DEC_HALO ? q : q + W;       // padded column index
+      const int sx = reflect_idx(col - DEC_HALO, W);
+      for (int y = tid >> 5; y < H; y += DEC_THREADS / 32) rawp[y * WP + col] = src[y * W + sx];
+    }
+  }
   __syncthreads();
+  DEC_STAMP(t1);
 
   // 2+3. separable float64 convolution -> float32 map in LDS + per-thread running argmax
   Best mine;
@@ -242,26 +328,43 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
   mine.i = 0x7fffffff;
   bool have = false;
   float *ocm = out_conv ? out_conv + (size_t)map * HW : nullptr;
+  unsigned long long *dbgp = nullptr;
+#ifdef PP_DEC_STAMPS
+  unsigned long long dbg_st[2] = {0, 0};
+  dbgp = dbg_st;
+#endif
   switch (r) {  // block-uniform
-    case 2: conv_passes<2>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    case 3: conv_passes<3>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    case 4: conv_passes<4>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    case 5: conv_passes<5>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    case 6: conv_passes<6>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    case 7: conv_passes<7>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    case 8: conv_passes<8>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
-    default: conv_passes<9>(buf, tmp, H, W, wk, ocm, mine.v, mine.i, have); break;
+    case 2: conv_passes<2>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 3: conv_passes<3>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 4: conv_passes<4>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 5: conv_passes<5>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 6: conv_passes<6>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 7: conv_passes<7>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 8: conv_passes<8>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    default: conv_passes<9>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
   }
   if (!have) {  // more threads than pixels: never wins
     mine.v = -__builtin_inff();
     mine.i = 0x7fffffff;
   }
+  DEC_STAMP(t2);
   __syncthreads();
   const Best b = block_argmax(mine, red);
+  DEC_STAMP(t3);
   if (tid == 0) {
     auto at = [&](int yy, int xx) { return buf[yy * W + xx]; };
     finalize(map, B, K, H, W, b.i, at, src, prob, vis, oks, err, den_x, den_y, in_w, in_h, o);
   }
+#ifdef PP_DEC_STAMPS
+  {
+    DEC_STAMP(t4);
+    if (tid == 0 && out_conv == nullptr) {
+      unsigned long long *d = reinterpret_cast<unsigned long long *>(o.locs + (size_t)2 * B * K) + (size_t)map * 8;
+      d[0] = t1 - t0; d[1] = t2 - t1; d[2] = t3 - t2; d[3] = t4 - t3; d[4] = t4 - t0; d[5] = t0; d[6] = r;
+      d[7] = ((dbg_st[0] - t1) << 32) | ((dbg_st[1] - dbg_st[0]) & 0xffffffffull);
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -328,7 +431,10 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_argmax_kernel(
 
 constexpr size_t LDS_LIMIT = 160 * 1024 - 256;
 
-static bool fits_lds(int H, int W) { return (size_t)H * W * 12 <= LDS_LIMIT; }
+static size_t lds_bytes(int H, int W) {
+  return (size_t)H * W * 8 + (size_t)H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) * 4;
+}
+static bool fits_lds(int H, int W) { return lds_bytes(H, W) <= LDS_LIMIT; }
 
 }  // namespace pp
 
@@ -353,7 +459,7 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   DecodeOut o{out_kpts, out_scores, out_locs, out_aux, out_err};
   const int maps = B * K;
   if (fits_lds(H, W)) {
-    const size_t lds = (size_t)H * W * 12;
+    const size_t lds = lds_bytes(H, W);
     static thread_local size_t attr_set = 0;
     if (lds > 64 * 1024 && lds > attr_set) {
       PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_lds_kernel),
