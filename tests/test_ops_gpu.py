@@ -36,10 +36,12 @@ def _tol(dtype, out_dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 768, 768), (300, 200, 128), (1, 17, 256), (257, 129, 64),
                                    (384, 2304, 768), (192, 96, 64), (193, 97, 128), (400, 400, 3072)])
 def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
+    if tile == 8 and dtype == torch.float32:
+        pytest.skip("256x256 tile is bf16-only")
     A, W = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, K ** -0.5)
     b = _rand((N,), torch.float32, 3)
     out = ops.linear(A, W, b, tile=tile)
@@ -78,7 +80,9 @@ def test_gemm_exact_integer_data_catches_layout_bugs(ops, dtype):
     g = torch.Generator().manual_seed(0)
     A = torch.randint(-3, 4, (M, K), generator=g).to(dtype).cuda()
     W = torch.randint(-3, 4, (N, K), generator=g).to(dtype).cuda()
-    for tile in (0, 1, 2, 3, 4, 5, 6, 7):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        if tile == 8 and dtype == torch.float32:
+            continue
         out = ops.linear(A, W, out_dtype=torch.float32, tile=tile)
         assert torch.equal(out.double(), A.double() @ W.double().t())
     # auto-selection picks the 192x96 tile when it saves a round of workgroups (M = 16 crops x 192)
@@ -98,7 +102,9 @@ def test_gemm_conv3x3_gather_batched_branches(ops, dtype):
     Wp = torch.stack([pack.conv_taps_major(wt[i].cpu()) for i in range(4)]).to(dtype).cuda()
     ro = pack.conv_gather_table(B, h, w, 3, 3, 1, 1, 4 * C).cuda()
     out = torch.empty((B * h * w, 4 * C), dtype=dtype, device="cuda")
-    for tile in (1, 2, 3, 4, 5, 6, 7):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
+        if tile == 8 and dtype == torch.float32:
+            continue
         out.zero_()
         ops.gemm(x, Wp, out, M=B * h * w, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C, bias=bias, rowoff=ro,
                  seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C, strideBias=C, tile=tile)
@@ -114,10 +120,12 @@ def _check_branches(x, Wp, bias, out, B, h, w, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("k", [4, 3, 2])
 def test_gemm_deconv_parities_scatter(ops, dtype, k, tile):
     from probpose_pytorch_amd import pack
+    if tile == 8 and dtype == torch.float32:
+        pytest.skip("256x256 tile is bf16-only")
     B, h, w, Cin, Cout = 2, 8, 6, 64, 128
     x = _rand((B * h * w, Cin), dtype, 1)
     wt = _rand((Cin, Cout, k, k), torch.float32, 2, (4 * Cin) ** -0.5)
