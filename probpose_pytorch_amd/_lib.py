@@ -12,6 +12,7 @@ PP_F32, PP_BF16 = 0, 1
 PP_MAX_RADIUS = 9
 PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS, EPI_HEATMAP = 1, 2, 4, 8, 16, 32, 64
+EPI_ROWSTATS, EPI_LNFOLD = 128, 256
 
 _lock = threading.Lock()
 _lib = None
@@ -32,7 +33,9 @@ class GemmArgs(C.Structure):
         ("strideA", C.c_longlong), ("strideW", C.c_longlong), ("strideC", C.c_longlong),
         ("strideBias", C.c_longlong), ("strideRowoff", C.c_longlong), ("strideRowmap", C.c_longlong),
         ("dtype", C.c_int), ("epilogue", C.c_int),
-        ("hm_K", C.c_int), ("hm_HW", C.c_int), ("hm_temperature", C.c_float), ("tile", C.c_int),
+        ("hm_K", C.c_int), ("hm_HW", C.c_int), ("hm_temperature", C.c_float),
+        ("C2", C.c_void_p), ("ldc2", C.c_int), ("stats_out", C.c_void_p), ("stats_in", C.c_void_p),
+        ("stats_parts", C.c_int), ("colsum", C.c_void_p), ("ln_eps", C.c_float), ("tile", C.c_int),
     ]
 
 

@@ -75,6 +75,13 @@ struct GemmParams {
   int hm_K, hm_HW;
   float hm_temperature;
   int tiles_m, tiles_n;
+  char *C2;          // PP_EPI_ROWSTATS: storage-dtype copy of the output rows
+  int ldc2;
+  float *stats_out;
+  const float *stats_in;
+  int stats_parts;
+  const float *colsum;
+  float ln_eps;
   int blocked;       // XCD-blocked tile order (large grids) vs plain order
   int lds_epilogue;  // bf16 C tile staged through LDS and stored as whole rows
 };
@@ -383,6 +390,42 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     }
   }
 
+  // ---- LayerNorm fold (consumer side): per-row mean / rstd from the producer's partial sums, and the
+  // column sums of W' = W diag(gamma); applied in the epilogue as rstd*(acc - mean*colsum) + bias.
+  float ln_mean[TM], ln_rstd[TM];
+  float4 cs4[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    ln_mean[i] = 0.f;
+    ln_rstd[i] = 1.f;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (VEC) {
+    if ((epi & PP_EPI_LNFOLD) && !is_producer) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = min(m0 + wm * (BM / WGM) + i * 16 + frow, p.M - 1);
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < p.stats_parts; ++q) {
+          const float2 t = *reinterpret_cast<const float2 *>(p.stats_in + ((size_t)m * p.stats_parts + q) * 2);
+          s1 += t.x;
+          s2 += t.y;
+        }
+        const float inv = 1.0f / (float)p.Kd;
+        const float mean = s1 * inv;
+        const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+        ln_mean[i] = mean;
+        ln_rstd[i] = 1.0f / sqrtf(var + p.ln_eps);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
+        if (n < p.N) cs4[j] = *reinterpret_cast<const float4 *>(p.colsum + n);
+      }
+    }
+  }
+
   // ---- main loop.  STAGES-1 K-tiles of DMA stay in flight across the barrier: the wait that
   // retires tile t is a COUNTED vmcnt (never 0 in steady state), then one raw s_barrier makes every
   // wave's pieces of tile t visible and proves every wave finished reading the buffer that tile
@@ -495,12 +538,15 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     // the staging buffers go through in NPASS column passes.  OES = output element size.
     auto lds_epilogue = [&]<int OES>(std::integral_constant<int, OES>) {
       constexpr int BUDGET = STAGES * STAGE_BYTES;
-      constexpr auto fits = [](int np) { return BM * (BN / np * OES + 16) + BM * 4 <= BUDGET && WGN % np == 0; };
+      constexpr auto fits = [](int np) {
+        return BM * (BN / np * OES + 16) + BM * 4 + BM * WGN * 8 <= BUDGET && WGN % np == 0;
+      };
       constexpr int NPASS = fits(1) ? 1 : (fits(2) ? 2 : 4);
       static_assert(fits(NPASS), "C tile must fit the staging buffers");
       constexpr int PBN = BN / NPASS;                  // columns per pass
       constexpr int CS = PBN * OES + 16;               // padded row stride: keeps 16-B alignment, spreads banks
       int *rows_lds = reinterpret_cast<int *>(smem + BM * CS);
+      float *stats_lds = reinterpret_cast<float *>(smem + BM * CS + BM * 4);   // [BM][WGN][2]
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
         __syncthreads();                             // K-loop reads (pass 0) / previous pass's row stores done
@@ -511,10 +557,19 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
           if (!mine) break;
           const int lr = wm * (BM / WGM) + i * 16 + frow;
           if (wn_in == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
+          float rs1 = 0.f, rs2 = 0.f;   // PP_EPI_ROWSTATS: this lane's share of the row sums
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
-                          acc[i][j][3] + bias4[j].w};
+            float v[4];
+            if (epi & PP_EPI_LNFOLD) {
+              v[0] = ln_rstd[i] * (acc[i][j][0] - ln_mean[i] * cs4[j].x) + bias4[j].x;
+              v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
+              v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
+              v[3] = ln_rstd[i] * (acc[i][j][3] - ln_mean[i] * cs4[j].w) + bias4[j].w;
+            } else {
+              v[0] = acc[i][j][0] + bias4[j].x; v[1] = acc[i][j][1] + bias4[j].y;
+              v[2] = acc[i][j][2] + bias4[j].z; v[3] = acc[i][j][3] + bias4[j].w;
+            }
             if (epi & PP_EPI_GELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
@@ -522,6 +577,24 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
             if (epi & PP_EPI_RELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (epi & PP_EPI_ROWSTATS) {
+              const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
+              if (n < p.N) {   // N % 4 == 0 on this path: the whole quad is in range
+                rs1 += (v[0] + v[1]) + (v[2] + v[3]);
+                rs2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                if (p.C2 && m0 + lr < p.M) {
+                  T *c2 = reinterpret_cast<T *>(p.C2) + (size_t)out_row[i] * p.ldc2 + n;
+                  if constexpr (sizeof(T) == 2) {
+                    uint2 pk;
+                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(c2) = pk;
+                  } else {
+                    *reinterpret_cast<float4 *>(c2) = make_float4(v[0], v[1], v[2], v[3]);
+                  }
+                }
+              }
             }
             char *dst = smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * OES;
             if constexpr (OES == 4) {
@@ -531,6 +604,16 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
               pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
               pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
               *reinterpret_cast<uint2 *>(dst) = pk;
+            }
+          }
+          if (epi & PP_EPI_ROWSTATS) {   // lanes (frow, fq = 0..3) of a wave share row lr
+            rs1 += __shfl_xor(rs1, 16, 64);
+            rs1 += __shfl_xor(rs1, 32, 64);
+            rs2 += __shfl_xor(rs2, 16, 64);
+            rs2 += __shfl_xor(rs2, 32, 64);
+            if (fq == 0) {
+              stats_lds[(lr * WGN + wn) * 2 + 0] = rs1;
+              stats_lds[(lr * WGN + wn) * 2 + 1] = rs2;
             }
           }
         }
@@ -543,6 +626,21 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
           if (r < 0 || cc >= ncols16) continue;
           const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
           *reinterpret_cast<uint4 *>(Cb + ((size_t)r * p.ldc + n0 + pass * PBN) * OES + cc * 16) = v;
+        }
+      }
+      if (epi & PP_EPI_ROWSTATS) {   // one partial (sum, sum of squares) per row for this column tile
+        __syncthreads();
+        for (int lr = tid; lr < BM; lr += NTHREADS) {
+          if (m0 + lr >= p.M) continue;
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int wq = 0; wq < WGN; ++wq) {
+            s1 += stats_lds[(lr * WGN + wq) * 2 + 0];
+            s2 += stats_lds[(lr * WGN + wq) * 2 + 1];
+          }
+          float *so = p.stats_out + ((size_t)rows_lds[lr] * p.stats_parts + tn) * 2;
+          so[0] = s1;
+          so[1] = s2;
         }
       }
     };
@@ -565,6 +663,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
                     acc[i][j][3] + bias4[j].w};
+      if (epi & PP_EPI_LNFOLD) {
+        v[0] = ln_rstd[i] * (acc[i][j][0] - ln_mean[i] * cs4[j].x) + bias4[j].x;
+        v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
+        v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
+        v[3] = ln_rstd[i] * (acc[i][j][3] - ln_mean[i] * cs4[j].w) + bias4[j].w;
+      }
       if (epi & PP_EPI_GELU) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (sizeof(T) == 2) ? gelu_fast(v[e]) : gelu_erf(v[e]);
@@ -646,6 +750,12 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   if (a->epilogue & PP_EPI_RESIDUAL) PP_REQUIRE(a->residual, "pp_gemm: PP_EPI_RESIDUAL without residual");
   if (a->epilogue & PP_EPI_ROWBIAS)
     PP_REQUIRE(a->rowbias && a->rowbias_period > 0, "pp_gemm: PP_EPI_ROWBIAS without rowbias/period");
+  if (a->epilogue & PP_EPI_LNFOLD)
+    PP_REQUIRE(a->stats_in && a->colsum && a->stats_parts > 0 && a->ln_eps > 0.f && !a->rowoff,
+               "pp_gemm: PP_EPI_LNFOLD needs stats_in, colsum, stats_parts, ln_eps and a plain (non-gather) A");
+  if (a->epilogue & PP_EPI_ROWSTATS)
+    PP_REQUIRE(a->stats_out && a->stats_parts > 0 && (!a->C2 || a->ldc2 % 4 == 0),
+               "pp_gemm: PP_EPI_ROWSTATS needs stats_out / stats_parts (and a 4-aligned ldc2)");
   if (a->epilogue & PP_EPI_HEATMAP)
     PP_REQUIRE(a->hm_K >= a->N && a->hm_HW > 0 && a->hm_temperature != 0.f, "pp_gemm: bad heatmap epilogue");
   GemmParams p;
@@ -665,6 +775,8 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.strideBias = a->strideBias; p.strideRowoff = a->strideRowoff; p.strideRowmap = a->strideRowmap;
   p.epilogue = a->epilogue;
   p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
+  p.C2 = (char *)a->C2; p.ldc2 = a->ldc2; p.stats_out = a->stats_out; p.stats_in = a->stats_in;
+  p.stats_parts = a->stats_parts; p.colsum = a->colsum; p.ln_eps = a->ln_eps;
   const int batch = a->batch > 0 ? a->batch : 1;
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
@@ -709,6 +821,11 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                          ? 1
                          : 0;
   }
+  if (a->epilogue & (PP_EPI_ROWSTATS | PP_EPI_LNFOLD))
+    PP_REQUIRE(vec && p.lds_epilogue, "pp_gemm: LayerNorm fusion needs the vector / LDS epilogue path (aligned N, ldc, C)");
+  if (a->epilogue & PP_EPI_ROWSTATS)
+    PP_REQUIRE(a->stats_parts == p.tiles_n, "pp_gemm: stats_parts=%d but this launch has %d column tiles",
+               a->stats_parts, p.tiles_n);
   dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
 #define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_)                                   \

@@ -11,8 +11,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_OUT_F32, EPI_RELU, EPI_RESIDUAL,  # noqa: F401
-                   EPI_ROWBIAS, PP_BF16, PP_F32)
+from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_LNFOLD, EPI_OUT_F32, EPI_RELU, EPI_RESIDUAL,  # noqa: F401
+                   EPI_ROWBIAS, EPI_ROWSTATS, PP_BF16, PP_F32)
 
 _DT = {torch.float32: PP_F32, torch.bfloat16: PP_BF16}
 
@@ -86,7 +86,8 @@ def _tune(a, key, out, residual):
 
 def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
-         strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0):
+         strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0,
+         ln_producer=None, ln_consumer=None):
     """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h."""
     a = _lib.GemmArgs()
     a.A, a.W, a.C = _p(A), _p(W), _p(out)
@@ -106,6 +107,19 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
     if heatmap is not None:
         epilogue |= EPI_HEATMAP
         a.hm_K, a.hm_HW, a.hm_temperature = heatmap
+    if ln_producer is not None:
+        # LayerNorm fusion, producer: (c2 copy [M, N] in the storage dtype or None, stats [M, parts, 2]);
+        # the 192-wide column tile fixes the number of partials per row
+        c2, stats = ln_producer
+        epilogue |= EPI_ROWSTATS
+        tile = 3
+        a.C2, a.ldc2 = _p(c2), (c2.stride(0) if c2 is not None else 0)
+        a.stats_out, a.stats_parts = _p(stats), stats.shape[1]
+    if ln_consumer is not None:
+        # LayerNorm fusion, consumer: (stats [M, parts, 2], colsum [N], eps)
+        stats, colsum, eps = ln_consumer
+        epilogue |= EPI_LNFOLD
+        a.stats_in, a.stats_parts, a.colsum, a.ln_eps = _p(stats), stats.shape[1], _p(colsum), float(eps)
     a.epilogue = epilogue
     a.tile = tile
     if tile == 0 and AUTOTUNE and M * N * Kd >= (1 << 24):
