@@ -125,11 +125,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // the ragged variant (VEC = false) keeps the element-wise paths.  Both are compile-time so the hot
 // plain-GEMM instantiation carries none of the gather / scalar code or its registers.
 //
+// LN: LayerNorm fusion compiled in (0 none, 1 producer = PP_EPI_ROWSTATS, 2 consumer = PP_EPI_LNFOLD); a
+// template mode so that every other instantiation carries none of its registers.
+//
 // NWP > 0 selects the wave-specialised form: WGM x WGN consumer waves that only read fragments and
 // issue MFMAs, plus NWP producer waves that only issue the LDS-DMA pieces.  A global_load_lds
 // blocks its wave for ~100-200 cycles while the CU's address unit drains (measured); with the DMA
 // on the MFMA-issuing waves that stall came straight out of the matrix pipe's issue time.
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0>
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0, int LN = 0>
 __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = (int)sizeof(T);
@@ -329,6 +332,16 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     }(std::make_integer_sequence<int, 2>{});
   };
 
+  // ---- pipeline fill first: the DMA of the first STAGES-1 K-tiles is in flight while the epilogue
+  // operands below (residual / bias / LayerNorm statistics) are fetched and reduced.  Those loads are
+  // YOUNGER than the fill, so the first counted wait of the K-loop over-waits (it also retires tile 1):
+  // safe, and tile 1 was issued together with tile 0 anyway.
+  if constexpr (NWP == 0) {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nkt) stage_all(s, s);
+  }
+
   // ---- every additive epilogue term (bias, pos-embed row bias, the fp32 residual that the proj/fc2
   // GEMMs update in place) is loaded straight INTO the accumulators before the K-loop: the loads are
   // older than every DMA piece, their latency hides under the pipeline fill, and the epilogue needs no
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (VEC) {
+  if constexpr (VEC && LN == 2) {
     if ((epi & PP_EPI_LNFOLD) && !is_producer) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -474,9 +487,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
       }
     }
   } else {
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nkt) stage_all(s, s);
   // the loads above (bias, row map) are older than every DMA piece: retire them once, here, so that
   // inside the loop only DMA pieces are outstanding and the counted waits are exact
 #ifdef PP_GEMM_STAMPS
@@ -539,7 +549,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     auto lds_epilogue = [&]<int OES>(std::integral_constant<int, OES>) {
       constexpr int BUDGET = STAGES * STAGE_BYTES;
       constexpr auto fits = [](int np) {
-        return BM * (BN / np * OES + 16) + BM * 4 + BM * WGN * 8 <= BUDGET && WGN % np == 0;
+        return BM * (BN / np * OES + 16) + BM * 4 + (LN == 1 ? BM * WGN * 8 : 0) <= BUDGET && WGN % np == 0;
       };
       constexpr int NPASS = fits(1) ? 1 : (fits(2) ? 2 : 4);
       static_assert(fits(NPASS), "C tile must fit the staging buffers");
@@ -561,7 +571,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             float v[4];
-            if (epi & PP_EPI_LNFOLD) {
+            if (LN == 2 && (epi & PP_EPI_LNFOLD)) {
               v[0] = ln_rstd[i] * (acc[i][j][0] - ln_mean[i] * cs4[j].x) + bias4[j].x;
               v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
               v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
@@ -578,22 +588,11 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (epi & PP_EPI_ROWSTATS) {
+            if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {
               const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
               if (n < p.N) {   // N % 4 == 0 on this path: the whole quad is in range
                 rs1 += (v[0] + v[1]) + (v[2] + v[3]);
                 rs2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                if (p.C2 && m0 + lr < p.M) {
-                  T *c2 = reinterpret_cast<T *>(p.C2) + (size_t)out_row[i] * p.ldc2 + n;
-                  if constexpr (sizeof(T) == 2) {
-                    uint2 pk;
-                    pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                    pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(c2) = pk;
-                  } else {
-                    *reinterpret_cast<float4 *>(c2) = make_float4(v[0], v[1], v[2], v[3]);
-                  }
-                }
               }
             }
             char *dst = smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * OES;
@@ -606,7 +605,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
               *reinterpret_cast<uint2 *>(dst) = pk;
             }
           }
-          if (epi & PP_EPI_ROWSTATS) {   // lanes (frow, fq = 0..3) of a wave share row lr
+          if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {   // lanes (frow, fq = 0..3) of a wave share row lr
             rs1 += __shfl_xor(rs1, 16, 64);
             rs1 += __shfl_xor(rs1, 32, 64);
             rs2 += __shfl_xor(rs2, 16, 64);
@@ -628,7 +627,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
           *reinterpret_cast<uint4 *>(Cb + ((size_t)r * p.ldc + n0 + pass * PBN) * OES + cc * 16) = v;
         }
       }
-      if (epi & PP_EPI_ROWSTATS) {   // one partial (sum, sum of squares) per row for this column tile
+      if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {   // one partial (sum, sum of squares) per row for this column tile
         __syncthreads();
         for (int lr = tid; lr < BM; lr += NTHREADS) {
           if (m0 + lr >= p.M) continue;
@@ -641,6 +640,51 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
           float *so = p.stats_out + ((size_t)rows_lds[lr] * p.stats_parts + tn) * 2;
           so[0] = s1;
           so[1] = s2;
+        }
+      }
+      if constexpr (LN == 1) if ((epi & PP_EPI_ROWSTATS) && p.C2) {
+        // storage-dtype copy of the output rows (the next GEMM's A operand), staged through LDS like C
+        constexpr int ES2 = (int)sizeof(T);
+        constexpr auto fits2 = [](int np) { return BM * (BN / np * ES2 + 16) + BM * 4 <= BUDGET && WGN % np == 0; };
+        constexpr int NP2 = fits2(1) ? 1 : (fits2(2) ? 2 : 4);
+        static_assert(fits2(NP2), "C2 tile must fit the staging buffers");
+        constexpr int PBN2 = BN / NP2, CS2 = PBN2 * ES2 + 16;
+        int *rows2 = reinterpret_cast<int *>(smem + BM * CS2);
+#pragma unroll
+        for (int pass = 0; pass < NP2; ++pass) {
+          __syncthreads();
+          const bool mine = !is_producer && (wn / (WGN / NP2)) == pass;
+          const int wn_in = wn - pass * (WGN / NP2);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            if (!mine) break;
+            const int lr = wm * (BM / WGM) + i * 16 + frow;
+            if (wn_in == 0 && fq == 0) rows2[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float v0 = acc[i][j][0] + bias4[j].x, v1 = acc[i][j][1] + bias4[j].y,
+                          v2 = acc[i][j][2] + bias4[j].z, v3 = acc[i][j][3] + bias4[j].w;
+              char *dst = smem + lr * CS2 + (wn_in * (BN / WGN) + j * 16 + fq * 4) * ES2;
+              if constexpr (ES2 == 4) {
+                *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+              } else {
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+                pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<uint2 *>(dst) = pk;
+              }
+            }
+          }
+          __syncthreads();
+          constexpr int CPR2 = PBN2 * ES2 / 16;
+          const int ncols16 = max(0, min(CPR2, (p.N - n0 - pass * PBN2) * ES2 / 16));
+          for (int c = tid; c < BM * CPR2; c += NTHREADS) {
+            const int lr = c / CPR2, cc = c - lr * CPR2;
+            const int r = rows2[lr];
+            if (r < 0 || cc >= ncols16) continue;
+            const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS2 + cc * 16);
+            *reinterpret_cast<uint4 *>(p.C2 + ((size_t)r * p.ldc2 + n0 + pass * PBN2) * ES2 + cc * 16) = v;
+          }
         }
       }
     };
@@ -663,7 +707,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
                     acc[i][j][3] + bias4[j].w};
-      if (epi & PP_EPI_LNFOLD) {
+      if (LN == 2 && (epi & PP_EPI_LNFOLD)) {
         v[0] = ln_rstd[i] * (acc[i][j][0] - ln_mean[i] * cs4[j].x) + bias4[j].x;
         v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
         v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
@@ -754,8 +798,10 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_REQUIRE(a->stats_in && a->colsum && a->stats_parts > 0 && a->ln_eps > 0.f && !a->rowoff,
                "pp_gemm: PP_EPI_LNFOLD needs stats_in, colsum, stats_parts, ln_eps and a plain (non-gather) A");
   if (a->epilogue & PP_EPI_ROWSTATS)
-    PP_REQUIRE(a->stats_out && a->stats_parts > 0 && (!a->C2 || a->ldc2 % 4 == 0),
+    PP_REQUIRE(a->stats_out && a->stats_parts > 0 && (!a->C2 || (a->ldc2 % 8 == 0 && ((uintptr_t)a->C2 & 15) == 0 && a->N % 8 == 0)),
                "pp_gemm: PP_EPI_ROWSTATS needs stats_out / stats_parts (and a 4-aligned ldc2)");
+  PP_REQUIRE(!((a->epilogue & PP_EPI_ROWSTATS) && (a->epilogue & PP_EPI_LNFOLD)),
+             "pp_gemm: a GEMM is either a LayerNorm producer or a consumer");
   if (a->epilogue & PP_EPI_HEATMAP)
     PP_REQUIRE(a->hm_K >= a->N && a->hm_HW > 0 && a->hm_temperature != 0.f, "pp_gemm: bad heatmap epilogue");
   GemmParams p;
@@ -828,19 +874,20 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                a->stats_parts, p.tiles_n);
   dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
-#define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_)                                   \
+#define PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_)                              \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
     static thread_local bool attr = false;                                                            \
     if (!attr) {                                                                                      \
       PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
-          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_>),    \
+          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
       attr = true;                                                                                    \
     }                                                                                                 \
-    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_>), grid,               \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_>), grid,          \
                        dim3(64 * (WGM_ * WGN_ + NWP_)), lds, s, p);                                   \
   } while (0)
+#define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_) PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, 0)
 #define PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_) PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, 0)
 #define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
   do {                                                                                                \
@@ -848,7 +895,30 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, false, true);                                 \
   } while (0)
   const bool gather = a->rowoff != nullptr;
-  if (!vec) {  // ragged N / heatmap epilogue: element-wise variant, 128x128 only
+  const int ln_mode = (a->epilogue & PP_EPI_ROWSTATS) ? 1 : ((a->epilogue & PP_EPI_LNFOLD) ? 2 : 0);
+  if (ln_mode && a->tile == 0 && !(cfg == 3 || (cfg == 2 && ln_mode == 2))) {
+    // auto-selection landed on a configuration without a LayerNorm-fused instantiation: use tile 3
+    cfg = 3;
+    p.tiles_m = cdiv(a->M, 192);
+    p.tiles_n = cdiv(a->N, 192);
+    const long long nb3 = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, 4);
+    p.blocked = nb3 >= 16 ? 1 : 0;
+    grid = dim3(p.blocked ? (unsigned)(((nb3 + 7) / 8) * 8 * 8 * 4) : (unsigned)(p.tiles_m * p.tiles_n), batch);
+  }
+  if (ln_mode) {
+    // LayerNorm-fused instantiations exist for the plain (non-gather) 192x192 tile, and for consumers the 192x96 tile
+    PP_REQUIRE(!gather && vec && (cfg == 3 || (cfg == 2 && ln_mode == 2)),
+               "pp_gemm: LayerNorm fusion is built for tile 3 (and tile 2 on the consumer side), got tile %d", cfg);
+    if (a->dtype == PP_BF16) {
+      if (ln_mode == 1) PP_LAUNCH_GEMM_L(bf16_t, 192, 192, 2, 4, 3, false, true, 0, 1);
+      else if (cfg == 3) PP_LAUNCH_GEMM_L(bf16_t, 192, 192, 2, 4, 3, false, true, 0, 2);
+      else PP_LAUNCH_GEMM_L(bf16_t, 192, 96, 2, 2, 2, false, true, 0, 2);
+    } else {
+      if (ln_mode == 1) PP_LAUNCH_GEMM_L(float, 192, 192, 2, 4, 3, false, true, 0, 1);
+      else if (cfg == 3) PP_LAUNCH_GEMM_L(float, 192, 192, 2, 4, 3, false, true, 0, 2);
+      else PP_LAUNCH_GEMM_L(float, 192, 96, 2, 2, 2, false, true, 0, 2);
+    }
+  } else if (!vec) {  // ragged N / heatmap epilogue: element-wise variant, 128x128 only
     if (a->dtype == PP_BF16) {
       if (gather) PP_LAUNCH_GEMM_V(bf16_t, 128, 128, 2, 2, 2, true, false);
       else PP_LAUNCH_GEMM_V(bf16_t, 128, 128, 2, 2, 2, false, false);
@@ -879,6 +949,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   }
 #undef PP_LAUNCH_GEMM_V
 #undef PP_LAUNCH_GEMM_W
+#undef PP_LAUNCH_GEMM_L
 #undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");
   return 0;

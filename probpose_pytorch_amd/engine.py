@@ -24,10 +24,12 @@ _PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 # so that per-launch event timings are not inflated by the other branch sharing the CUs
 SERIALIZE_HEAD = False
 
-# bf16 plans fold every in-block LayerNorm into the neighbouring GEMMs (producer epilogue: bf16 copy of
-# the residual row + per-row partial sums; consumer epilogue: rstd*(acc - mean*colsum) + bias'), which
-# removes 24 of the 25 LayerNorm launches of a ViT-B forward.  fp32 (parity) plans keep the LN kernel.
-FUSE_LAYERNORM = True
+# Optional: bf16 plans can fold every in-block LayerNorm into the neighbouring GEMMs (producer epilogue:
+# bf16 copy of the residual row + per-row partial sums; consumer epilogue: rstd*(acc - mean*colsum) +
+# bias'), which removes 24 of the 25 LayerNorm launches of a ViT-B forward.  Measured on MI355X at bs 64
+# it is a net LOSS (the fused epilogues cost +11..16 us per GEMM, the LayerNorm kernel they replace only
+# 13-15 us at 4.4 TB/s), so it is off by default; fp32 (parity) plans never use it.
+FUSE_LAYERNORM = False
 
 
 def _signature(module: torch.nn.Module):
