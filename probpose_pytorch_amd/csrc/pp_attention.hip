@@ -16,8 +16,10 @@
 // The k-slot order inside each 32-key MFMA step is permuted identically on both
 // operands (slot (g,j) <-> key 4g + j for j < 4, 16 + 4g + (j-4) otherwise),
 // which is what makes the accumulator directly reusable.
-// Everything else (fp32 parity mode, other head dims, N > 192) runs the exact
-// fp32 VALU kernel in pp_ops.hip.
+// attention_stream_kernel is the same computation for any N and head_dim 32 / 64 / 80 (ViT-H: N = 432
+// at 384x288, hd = 80): one workgroup per (crop, head, block of 128 queries), the keys stream
+// through LDS in blocks of 96 with the online-softmax rescale between blocks.
+// Everything else (fp32 parity mode, other head dims) runs the exact fp32 VALU kernel in pp_ops.hip.
 #include "pp_common.h"
 
 namespace pp {
@@ -36,12 +38,16 @@ template <int HD> struct AttGeom {
   static constexpr int KROW = HD * 2;                 // bytes per K / V row in LDS (128 or 64)
   static constexpr int LDS = 2 * AT_NMAX * KROW;      // K + V, row-major
   static constexpr int CHUNKS = HD / 8;               // 16-B chunks per row
-  static constexpr int KS = HD / 32;                  // 32-deep MFMA steps of the first product
+  static constexpr int KS = (HD + 31) / 32;           // 32-deep MFMA steps of the first product (hd 80: the last is half empty)
+  static constexpr int KLIVE = (HD % 32) ? (HD % 32) / 8 : 4;  // lane quartets (g) that carry data in the last step
   static constexpr int DT = HD / 16;                  // 16-dim output tiles
-  static constexpr int RPP = 1024 / KROW;             // rows per 1-KiB DMA piece
-  // 16-B chunk swizzle that makes a 16-row ds_read_b128 column hit 16 distinct bank slots
+  static constexpr int RPP = 1024 / KROW;             // rows per 1-KiB DMA piece (one-shot kernel: HD 32 / 64 only)
+  // 16-B chunk swizzle that makes a 16-row ds_read_b128 column hit 16 distinct bank slots.  160-B rows
+  // (hd 80) need none: row r starts at bank slot 10 r mod 16, and the b128 lane groups (rows {0-3,12-15}
+  // at chunk c with rows {4-11} at chunk c+1) as well as the 8 rows x 32 B of a transposing read
+  // (40 r mod 64 dwords) already land on distinct banks.
   static __device__ __forceinline__ int swz(int row, int chunk) {
-    return HD == 64 ? (chunk ^ (row & 7)) : (chunk ^ ((row >> 2) & 3));
+    return HD == 64 ? (chunk ^ (row & 7)) : (HD == 32 ? (chunk ^ ((row >> 2) & 3)) : chunk);
   }
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -269,6 +275,192 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
 #endif
 }
 
+// ---- streaming form: any N, head_dim 32 / 64 / 80.  Workgroup = 4 waves x ST_QT query tiles = 128
+// queries of one (crop, head); key blocks of ST_KB = 96 rows of K and V go HBM/L2 -> LDS by LDS-DMA
+// (single-buffered: three workgroups share a CU and cover each other's load phases), then exactly the
+// block body of the kernel above.  Rows are addressed block-relative in LDS; masks use the global key.
+constexpr int ST_QT = 2;
+constexpr int ST_KB = 96;
+template <int HD>
+__global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *__restrict__ qkv,
+                                                                  bf16_t *__restrict__ out, int N, int heads,
+                                                                  int qblocks, float scale_log2e) {
+  using G = AttGeom<HD>;
+  constexpr int KROW = G::KROW;
+  constexpr int BLK_BYTES = ST_KB * KROW;
+  static_assert(BLK_BYTES % 1024 == 0, "a key block is a whole number of 1-KiB DMA pieces");
+  constexpr int NPIECE = BLK_BYTES / 1024;
+  constexpr int KB_TILES = ST_KB / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *Ks = smem;
+  char *Vs = smem + BLK_BYTES;
+  const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks;
+  const int b = bh / heads, h = bh - b * heads;
+  const int C = heads * HD, ld = 3 * C;
+  const bf16_t *base = qkv + (size_t)b * N * ld + h * HD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+  // Q fragments (B operand): lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]; dims >= HD are zero
+  const int q0 = (qb * 4 + wave) * (ST_QT * 16);
+  uint4 qf[ST_QT][G::KS];
+#pragma unroll
+  for (int t = 0; t < ST_QT; ++t) {
+    const int q = q0 + t * 16 + lrow;
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+      qf[t][s] = make_uint4(0, 0, 0, 0);
+      if (q < N && (s < G::KS - 1 || g < G::KLIVE))
+        qf[t][s] = *reinterpret_cast<const uint4 *>(base + (size_t)q * ld + s * 32 + g * 8);
+    }
+  }
+  float m_run[ST_QT], l_run[ST_QT];
+  f32x4 oacc[G::DT][ST_QT];
+#pragma unroll
+  for (int t = 0; t < ST_QT; ++t) {
+    m_run[t] = -__builtin_inff();
+    l_run[t] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) oacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nkb = (N + ST_KB - 1) / ST_KB;   // every block holds at least one real key
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb > 0) __syncthreads();             // every wave has finished reading the previous block
+    // ---- K / V block -> LDS: piece p = 64 consecutive 16-B chunks of the row-major block image
+#pragma unroll
+    for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
+      const int pc = j * 4 + wave;
+      if (pc < NPIECE) {
+        const int c = pc * 64 + lane;
+        const int row = c / G::CHUNKS, pchunk = c - row * G::CHUNKS;
+        const int key = kb * ST_KB + row;
+        const bf16_t *src = base + (size_t)key * ld + G::swz(row, pchunk) * 8;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + pc * 1024);
+        const void *zsrc = g_att_zero + lane * 16;
+        att_glds16(key < N ? (const void *)(src + C) : zsrc, dst);
+        att_glds16(key < N ? (const void *)(src + 2 * C) : zsrc, dst + BLK_BYTES);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- S^T block = K_block Q^T
+    f32x4 sacc[KB_TILES][ST_QT];
+#pragma unroll
+    for (int kt = 0; kt < KB_TILES; ++kt) {
+      const int key_lo = kb * ST_KB + kt * 16 + g * 4;
+      const f32x4 init = f32x4{key_lo + 0 < N ? 0.f : -__builtin_inff(), key_lo + 1 < N ? 0.f : -__builtin_inff(),
+                               key_lo + 2 < N ? 0.f : -__builtin_inff(), key_lo + 3 < N ? 0.f : -__builtin_inff()};
+#pragma unroll
+      for (int t = 0; t < ST_QT; ++t) sacc[kt][t] = init;
+      const int r = kt * 16 + lrow;
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s) {
+        uint4 kf = make_uint4(0, 0, 0, 0);
+        if (s < G::KS - 1 || g < G::KLIVE)
+          kf = *reinterpret_cast<const uint4 *>(Ks + r * KROW + (G::swz(r, 4 * s + g) << 4));
+#pragma unroll
+        for (int t = 0; t < ST_QT; ++t)
+          sacc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&kf),
+                                                                *reinterpret_cast<const bf16x8 *>(&qf[t][s]),
+                                                                sacc[kt][t], 0, 0, 0);
+      }
+    }
+    // ---- online softmax over the block (see the one-shot kernel)
+#pragma unroll
+    for (int t = 0; t < ST_QT; ++t) {
+      float mb = sacc[0][t][0];
+#pragma unroll
+      for (int kt = 0; kt < KB_TILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mb = fmaxf(mb, sacc[kt][t][r]);
+      mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+      mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+      const float m_new = fmaxf(m_run[t], mb * scale_log2e);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KB_TILES; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], scale_log2e, -m_new));
+          sacc[kt][t][r] = pv;
+          l += pv;
+        }
+      l_run[t] = l_run[t] * alpha + l;
+      m_run[t] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        oacc[dt][t][0] *= alpha; oacc[dt][t][1] *= alpha; oacc[dt][t][2] *= alpha; oacc[dt][t][3] *= alpha;
+      }
+    }
+    // ---- O^T += V_block^T P_block^T
+#pragma unroll
+    for (int u = 0; u < KB_TILES / 2; ++u) {
+      uint4 pf[ST_QT];
+#pragma unroll
+      for (int t = 0; t < ST_QT; ++t) {
+        pf[t].x = pack_bf16x2(sacc[2 * u][t][0], sacc[2 * u][t][1]);
+        pf[t].y = pack_bf16x2(sacc[2 * u][t][2], sacc[2 * u][t][3]);
+        pf[t].z = pack_bf16x2(sacc[2 * u + 1][t][0], sacc[2 * u + 1][t][1]);
+        pf[t].w = pack_bf16x2(sacc[2 * u + 1][t][2], sacc[2 * u + 1][t][3]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        const int tq = lrow >> 2, tp = lrow & 3;
+        const int key0 = 32 * u + 4 * g + tq;            // block-relative row
+        const int ch = 2 * dt + (tp >> 1);
+        const int a0 = key0 * KROW + (G::swz(key0, ch) << 4) + (tp & 1) * 8;
+        const int key1 = key0 + 16;
+        const int a1 = key1 * KROW + (G::swz(key1, ch) << 4) + (tp & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(Vs + a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4 *)(Vs + a1));
+        uint4 vf;
+        vf.x = (unsigned)(unsigned short)lo[0] | ((unsigned)(unsigned short)lo[1] << 16);
+        vf.y = (unsigned)(unsigned short)lo[2] | ((unsigned)(unsigned short)lo[3] << 16);
+        vf.z = (unsigned)(unsigned short)hi[0] | ((unsigned)(unsigned short)hi[1] << 16);
+        vf.w = (unsigned)(unsigned short)hi[2] | ((unsigned)(unsigned short)hi[3] << 16);
+#pragma unroll
+        for (int t = 0; t < ST_QT; ++t)
+          oacc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&vf),
+                                                                *reinterpret_cast<const bf16x8 *>(&pf[t]),
+                                                                oacc[dt][t], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < ST_QT; ++t) {
+    float l = l_run[t];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.0f / l;
+    const int q = q0 + t * 16 + lrow;
+    if (q >= N) continue;
+    bf16_t *orow = out + ((size_t)b * N + q) * C + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) {
+      uint2 pk;
+      pk.x = pack_bf16x2(oacc[dt][t][0] * inv_l, oacc[dt][t][1] * inv_l);
+      pk.y = pack_bf16x2(oacc[dt][t][2] * inv_l, oacc[dt][t][3] * inv_l);
+      *reinterpret_cast<uint2 *>(orow + dt * 16 + g * 4) = pk;
+    }
+  }
+}
+
+template <int HD>
+static void launch_stream(const void *qkv, void *out, int B, int N, int heads, hipStream_t s) {
+  const int qblocks = (N + 4 * ST_QT * 16 - 1) / (4 * ST_QT * 16);
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
+  hipLaunchKernelGGL(attention_stream_kernel<HD>, dim3((unsigned)((size_t)B * heads * qblocks)), dim3(256),
+                     2 * ST_KB * AttGeom<HD>::KROW, s, (const bf16_t *)qkv, (bf16_t *)out, N, heads, qblocks,
+                     scale_log2e);
+}
+
 }  // namespace pp
 
 extern "C" int pp_attention(const void *qkv, void *out, int B, int N, int heads, int hd, int dtype,
@@ -288,6 +480,14 @@ extern "C" int pp_attention(const void *qkv, void *out, int B, int N, int heads,
         hipLaunchKernelGGL(attention_mfma_kernel<32>, dim3(B * heads), dim3(256), AttGeom<32>::LDS, s,
                            (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e);
       PP_CHECK_LAUNCH("attention_mfma_kernel");
+      return 0;
+    }
+    if ((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 &&
+        (size_t)B * heads * ((N + 127) / 128) < (1ull << 31)) {
+      if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, s);
+      else if (hd == 64) launch_stream<64>(qkv, out, B, N, heads, s);
+      else launch_stream<32>(qkv, out, B, N, heads, s);
+      PP_CHECK_LAUNCH("attention_stream_kernel");
       return 0;
     }
     return attention_valu<bf16_t>(qkv, out, B, N, heads, hd, s);

@@ -30,6 +30,9 @@ SERIALIZE_HEAD = False
 # it is a net LOSS (the fused epilogues cost +11..16 us per GEMM, the LayerNorm kernel they replace only
 # 13-15 us at 4.4 TB/s), so it is off by default; fp32 (parity) plans never use it.
 FUSE_LAYERNORM = False
+# Run the ViT blocks of a batch as two half-batch kernel chains on two HIP streams (see VitPlan.forward_tokens).
+DUAL_CHAIN = False
+DUAL_CHAIN_MIN_BATCH = 16
 
 
 def _signature(module: torch.nn.Module):
@@ -114,6 +117,7 @@ class VitPlan:
         self.neps = vit.norm.eps
         self.hidden = self.blocks[0]["fc1_w"].shape[0] if self.blocks else 4 * C
         self.ws = _Workspace()
+        self._chain_stream = None
 
     def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
         """x (B,3,H,W) f32 on the device -> tokens [B*N, C] in the compute dtype
@@ -131,14 +135,45 @@ class VitPlan:
         ao = g("ao", (M, C), dt, dev)
         hid = g("hid", (M, self.hidden), dt, dev)
         feats = g("feats", (M, C), dt, dev)
-        ops.patchify(x, a0, self.patch)
         if self.fuse_ln:
+            ops.patchify(x, a0, self.patch)
             return self._forward_tokens_fused(B, M, a0, xres, qkv, ao, hid, feats)
+        bufs = (a0, xres, h, qkv, ao, hid, feats)
+        if DUAL_CHAIN and not SERIALIZE_HEAD and B % 2 == 0 and B >= DUAL_CHAIN_MIN_BATCH:
+            # Two half-batches as two independent kernel chains on two HIP streams (row slices of the same
+            # buffers, same weights).  Every kernel of the path is bulk-synchronous: all its workgroups
+            # run their matrix phase together and then their store phase together, so one chain alone
+            # alternates between an idle HBM and an idle matrix pipe.  The second chain starts one
+            # GEMM later, so its memory phases fall into the first chain's matrix phases, and each
+            # chain's tail wave is filled by the other chain's next kernel.
+            if self._chain_stream is None:
+                self._chain_stream = torch.cuda.Stream(device=dev)
+            cur, s2 = torch.cuda.current_stream(dev), self._chain_stream
+            Bh, Mh = B // 2, M // 2
+            offset = torch.cuda.Event()
+            self._run_chain(x[:Bh], Bh, tuple(t[:Mh] for t in bufs), offset)
+            s2.wait_event(offset)
+            with torch.cuda.stream(s2):
+                self._run_chain(x[Bh:], Bh, tuple(t[Mh:] for t in bufs))
+            cur.wait_stream(s2)
+        else:
+            self._run_chain(x, B, bufs)
+        return feats
+
+    def _run_chain(self, x, B, bufs, offset_event=None):
+        a0, xres, h, qkv, ao, hid, feats = bufs
+        C, N = self.C, self.N
+        M = B * N
+        ops.patchify(x, a0, self.patch)
         # patch_embed.proj as a GEMM, + bias, + pos_embed (row m uses pos[m % N]), fp32 residual stream
         ops.gemm(a0, self.pe_w, xres, M=M, N=C, Kd=a0.shape[1], lda=a0.shape[1], ldw=a0.shape[1], ldc=C,
                  bias=self.pe_b, rowbias=self.pos, rowbias_period=N, epilogue=EPI_OUT_F32)
-        for b in self.blocks:
+        if offset_event is not None and not self.blocks:
+            offset_event.record()
+        for i, b in enumerate(self.blocks):
             ops.layernorm(xres, b["n1w"], b["n1b"], b["eps1"], h)
+            if i == 0 and offset_event is not None:
+                offset_event.record()      # the other chain starts here: one patch-embed GEMM + LN behind
             ops.linear(h, b["qkv_w"], b["qkv_b"], out=qkv)
             ops.attention(qkv, ao, B, N, self.heads, self.hd)
             ops.linear(ao, b["proj_w"], b["proj_b"], out=xres, residual=xres)
@@ -146,7 +181,6 @@ class VitPlan:
             ops.linear(h, b["fc1_w"], b["fc1_b"], out=hid, epilogue=EPI_GELU)
             ops.linear(hid, b["fc2_w"], b["fc2_b"], out=xres, residual=xres)
         ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
-        return feats
 
 
 def _vit_forward_tokens_fused(self, B, M, a0, xres, qkv, ao, hid, feats):

@@ -225,7 +225,8 @@ def test_layernorm(ops, dtype, rows, C):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,heads,hd", [(2, 192, 12, 64), (1, 192, 12, 32), (2, 432, 2, 80), (3, 12, 2, 64),
-                                          (1, 70, 3, 32)])
+                                          (1, 70, 3, 32), (1, 432, 3, 64), (2, 200, 2, 32), (1, 97, 2, 80),
+                                          (1, 1000, 1, 80), (2, 577, 2, 64), (1, 193, 1, 80), (2, 5, 1, 80)])
 def test_attention(ops, dtype, B, N, heads, hd):
     C = heads * hd
     qkv = _rand((B * N, 3 * C), dtype, 1)
