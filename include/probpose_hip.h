@@ -37,7 +37,7 @@ extern "C" {
 
 /* epilogue flags of pp_gemm (bit-or) */
 #define PP_EPI_BIAS 1                   /* + bias[n]                                  */
-#define PP_EPI_GELU 2                   /* exact-erf GELU (timm Mlp act)              */
+#define PP_EPI_GELU 2                   /* GELU (timm Mlp act): exact erf in f32 mode; bf16 mode: fitted form, abs err <= 3e-5 */
 #define PP_EPI_RELU 4                   /* ReLU (head.py:120)                         */
 #define PP_EPI_RESIDUAL 8               /* out_f32 = residual_f32 + (acc + bias)      */
 #define PP_EPI_OUT_F32 16               /* store fp32 regardless of the storage dtype */
@@ -74,7 +74,8 @@ int pp_device_ok(void);
  * scores f32 [B,K] (raw heatmap at the integer peak), locs f32 [B,K,2]
  * (heatmap space, = get_heatmap_expected_value's locs), aux f32 [3,B,K]
  * (prob,vis,oks passthrough), err f64 [B,K] (= err / sqrt(H^2+W^2)),
- * conv f32 [B,K,H,W] (return_heatmap=True).
+ * conv f32 [B,K,H,W] (return_heatmap=True), packed f64 [B,K,7] = (kpt x, kpt y,
+ * score, prob, vis, oks, err) per keypoint: the record the multi-GPU all-gather ships.
  * workspace: pp_decode_workspace_bytes() bytes (0 when the map fits in LDS).
  * ---------------------------------------------------------------------- */
 size_t pp_decode_workspace_bytes(int B, int K, int H, int W);
@@ -83,7 +84,7 @@ int pp_decode_f32(const float *heatmaps, const float *prob, const float *vis,
                   const double *taps, const int *radius, double den_x, double den_y,
                   double in_w, double in_h, double *out_kpts, float *out_scores,
                   float *out_locs, float *out_aux, double *out_err, float *out_conv,
-                  void *workspace, void *stream);
+                  double *out_packed, void *workspace, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense contraction on MFMA:  C[M,N] = epilogue(A[M,Kd] * W[N,Kd]^T).

@@ -45,7 +45,7 @@ _SIGNATURES = {
     "pp_last_error": (C.c_char_p, []),
     "pp_device_ok": (C.c_int, []),
     "pp_decode_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "pp_decode_f32": (C.c_int, [_vp] * 5 + [_i] * 4 + [_vp, _vp] + [_d] * 4 + [_vp] * 8),
+    "pp_decode_f32": (C.c_int, [_vp] * 5 + [_i] * 4 + [_vp, _vp] + [_d] * 4 + [_vp] * 9),
     "pp_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "pp_layernorm": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "pp_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -75,6 +75,7 @@ struct DecodeOut {
   float *locs;
   float *aux;
   double *err;
+  double *packed;   // [B*K][7] f64: x, y (input space), score, prob, vis, oks, err: the record the all-gather ships
 };
 
 // Everything after the argmax; one thread.  c(y,x) reads the float32 convolved map.
@@ -115,6 +116,16 @@ __device__ __forceinline__ void finalize(int map, int B, int K, int H, int W, in
   }
   if (o.err && err)  // codec.py:260-261: float32 / np.float64 scalar -> float64
     o.err[map] = (double)err[map] / sqrt((double)(H * H + W * W));
+  if (o.packed) {   // every field exactly as above, widened to f64 (lossless for the f32 ones)
+    double *r = o.packed + (size_t)map * 7;
+    r[0] = (double)fx / den_x * in_w;
+    r[1] = (double)fy / den_y * in_h;
+    r[2] = (double)raw_map[y * W + x];
+    r[3] = prob ? (double)prob[map] : 0.0;
+    r[4] = vis ? (double)vis[map] : 0.0;
+    r[5] = oks ? (double)oks[map] : 0.0;
+    r[6] = err ? (double)err[map] / sqrt((double)(H * H + W * W)) : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -448,7 +459,7 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
                              const double *taps, const int *radius, double den_x, double den_y,
                              double in_w, double in_h, double *out_kpts, float *out_scores,
                              float *out_locs, float *out_aux, double *out_err, float *out_conv,
-                             void *workspace, void *stream) {
+                             double *out_packed, void *workspace, void *stream) {
   using namespace pp;
   PP_REQUIRE(B >= 0 && K > 0 && H > 0 && W > 0, "pp_decode_f32: bad shape B=%d K=%d H=%d W=%d", B, K,
              H, W);
@@ -456,7 +467,7 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   PP_REQUIRE(heatmaps && taps && radius, "pp_decode_f32: null input");
   PP_REQUIRE((long long)H * W < (1ll << 30), "pp_decode_f32: map too large");
   hipStream_t s = (hipStream_t)stream;
-  DecodeOut o{out_kpts, out_scores, out_locs, out_aux, out_err};
+  DecodeOut o{out_kpts, out_scores, out_locs, out_aux, out_err, out_packed};
   const int maps = B * K;
   if (fits_lds(H, W)) {
     const size_t lds = lds_bytes(H, W);

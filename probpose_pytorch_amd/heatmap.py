@@ -89,6 +89,8 @@ def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=Non
                                  f"got {t.numel()} for B={B}, K={K}")
         out["aux"] = torch.empty((3, B, K), dtype=torch.float32, device=dev)
         out["err"] = torch.empty((B, K), dtype=torch.float64, device=dev)
+        if input_size is not None:
+            out["packed"] = torch.empty((B, K, 7), dtype=torch.float64, device=dev)
     if want_conv:
         out["conv"] = torch.empty_like(heatmaps)
     ws_bytes = L.pp_decode_workspace_bytes(B, K, H, W)
@@ -100,7 +102,7 @@ def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=Non
             B, K, H, W, _lib.ptr(taps), _lib.ptr(radius), den_x, den_y, in_w, in_h,
             _lib.ptr(out.get("kpts")), _lib.ptr(out["scores"]), _lib.ptr(out["locs"]),
             _lib.ptr(out.get("aux")), _lib.ptr(out.get("err")), _lib.ptr(out.get("conv")),
-            _lib.ptr(ws), _lib.stream_ptr()))
+            _lib.ptr(out.get("packed")), _lib.ptr(ws), _lib.stream_ptr()))
     _lib.check(rc, "pp_decode_f32")
     return out
 

@@ -57,6 +57,24 @@ _TUNE_CACHE: dict = {}
 _TUNE_CANDIDATES = (2, 3, 4, 5, 7)
 
 
+def save_tune_cache(path: str) -> None:
+    """Persist the per-shape winners (JSON) so that a later process (e.g. a profiled run) starts tuned."""
+    import json
+    rows = [[*(str(v) if isinstance(v, torch.dtype) else v for v in k), best] for k, best in _TUNE_CACHE.items()]
+    with open(path, "w") as f:
+        json.dump(rows, f)
+
+
+def load_tune_cache(path: str) -> int:
+    import json
+    with open(path) as f:
+        rows = json.load(f)
+    names = {str(d): d for d in (torch.bfloat16, torch.float32)}
+    for r in rows:
+        _TUNE_CACHE[tuple(names.get(v, v) if isinstance(v, str) else v for v in r[:-1])] = int(r[-1])
+    return len(rows)
+
+
 def _tune(a, key, out, residual):
     L = _lib.lib()
     stream = _lib.stream_ptr()
@@ -70,9 +88,10 @@ def _tune(a, key, out, residual):
         a.tile = cand
         if L.pp_gemm(C.byref(a), stream) != 0:      # configuration not applicable to this problem
             continue
+        L.pp_gemm(C.byref(a), stream)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        for _ in range(3):
+        for _ in range(5):
             L.pp_gemm(C.byref(a), stream)
         e.record()
         e.synchronize()

@@ -29,6 +29,8 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
 
 def pack_decoded(out: Dict[str, torch.Tensor]) -> torch.Tensor:
     """Decode outputs (Codec.decode_device) -> one float64 tensor [B, K, 7] (lossless for the f32 fields)."""
+    if "packed" in out:          # written by the decode kernel itself
+        return out["packed"]
     kpts = out["kpts"]
     B, K, _ = kpts.shape
     packed = torch.empty((B, K, 7), dtype=torch.float64, device=kpts.device)

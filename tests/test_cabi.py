@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu(built_lib):
     """Host-side checks run before any launch, so they can be exercised on CPU."""
     from probpose_pytorch_amd import _lib
     rc = built_lib.pp_decode_f32(None, None, None, None, None, 1, 17, 64, 48, None, None,
-                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None)
+                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, None)
     assert rc != 0 and b"null" in built_lib.pp_last_error()
     assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == 0
     assert built_lib.pp_decode_workspace_bytes(1, 20, 256, 256) == 20 * 256 * 256 * 12

@@ -144,6 +144,21 @@ def test_empty_batch(pp):
     assert kpts.shape == (0, 17, 2) and scores.shape == (0, 17) and prob.shape == (0, 1, 17)
 
 
+def test_packed_record_equals_separate_outputs(pp):
+    """The [B,K,7] f64 record the kernel writes for the all-gather == the separately written fields."""
+    from probpose_pytorch_amd import parallel
+    B, K = 5, 17
+    codec = pp.Codec(pp.ProbMap((192, 256), (48, 64), orc.COCO17_SIGMAS))
+    hm = torch.from_numpy(orc.synthetic_heatmaps(B, K, 64, 48, seed=3)).cuda()
+    g = torch.Generator().manual_seed(9)
+    aux = tuple(torch.rand((B, K, 1, 1), generator=g).cuda() for _ in range(4))
+    out = codec.decode_device((hm,) + aux)
+    assert out["packed"].shape == (B, K, 7) and out["packed"].dtype == torch.float64
+    rebuilt = parallel.pack_decoded({k: v for k, v in out.items() if k != "packed"})
+    assert torch.equal(out["packed"], rebuilt)
+    assert parallel.pack_decoded(out) is out["packed"]
+
+
 def test_full_size_batch_properties(pp):
     """BASELINE sizes (B=64 K=17 64x48 and 128 crops K=133 96x72): too slow for the
     scipy oracle as a whole, so check size-independent properties + a sampled

@@ -9,7 +9,11 @@ import torch
 import __graft_entry__ as g
 
 g.build()
-from probpose_pytorch_amd import ops
+from probpose_pytorch_amd import _lib, ops
+
+if "--lib" in sys.argv:      # A/B an experimental build of the library (tools/build_exp.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+TILES = tuple(int(t) for t in sys.argv[sys.argv.index("--tiles") + 1].split(",")) if "--tiles" in sys.argv else (3,)
 
 
 def bench(fn, iters=20):
@@ -43,7 +47,7 @@ def main():
         b = torch.randn((N,), generator=gen).cuda()
         res = torch.randn((Mm, N), generator=gen).cuda() if resid else None
         out = res if resid else torch.empty((Mm, N), dtype=dt, device="cuda")
-        for tile in (3, 8):
+        for tile in TILES:
             t = bench(lambda: ops.linear(A, W, b, out=out, epilogue=epi, residual=res, tile=tile))
             rows.append((name, tile, t, 2.0 * Mm * N * K / t / 1e6))
     for r in rows:

@@ -106,12 +106,17 @@ int main() {
   CHECK(hipMemset(c.a, 1, bytes));
   CHECK(hipMemset(c.b, 2, bytes));
   const char *names[3] = {"read ", "write", "copy "};
-  for (int m = 0; m < 3; ++m) {
-    c.mode = m;
-    const float ms = timeit(run_stream, &c, 10);
-    const double moved = (m == 2 ? 2.0 : 1.0) * bytes;
-    printf("HBM %s 2 GiB: %.3f ms  %.0f GB/s\n", names[m], ms, moved / ms / 1e6);
-  }
+  // 2 GiB streams from / to HBM; the smaller working sets are re-touched every launch and show what the
+  // 256 MB Infinity Cache (and, at 16 MB, the 8 x 4 MB L2s) add
+  const size_t sizes[5] = {bytes, (size_t)512 << 20, (size_t)128 << 20, (size_t)48 << 20, (size_t)16 << 20};
+  for (int zi = 0; zi < 5; ++zi)
+    for (int m = 0; m < 3; ++m) {
+      c.mode = m;
+      c.n = sizes[zi] / 16;
+      const float ms = timeit(run_stream, &c, zi == 0 ? 10 : 50);
+      const double moved = (m == 2 ? 2.0 : 1.0) * sizes[zi];
+      printf("stream %s %5zu MiB per buffer: %.4f ms  %.0f GB/s\n", names[m], sizes[zi] >> 20, ms, moved / ms / 1e6);
+    }
   // MFMA
   unsigned short *h = (unsigned short *)malloc(4096 * 16);
   CHECK(hipMalloc(&c.opnd, 4096 * 16));
