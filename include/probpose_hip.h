@@ -172,6 +172,28 @@ int pp_tokens_to_nchw(const void *x, float *out, int B, int N, int C, int dtype,
  * ProbMapHead.forward is called on a foreign NCHW feature map). */
 int pp_nchw_to_tokens(const float *x, void *out, int B, int C, int HW, int dtype, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Front end: person boxes of one RGB frame -> network input crops.  Replaces
+ *   dataset.py:71-90   scale_box: image.crop(box).resize(image_size, PIL.Image.LANCZOS)
+ *   inference.py:74-82 image.resize(input_size, LANCZOS), v2.ToImage(), v2.ToDtype(float32, scale=True)
+ * (the arithmetic is Pillow's: Image.crop zero-pads outside the frame; ImagingResample, 8 bits per
+ * channel, Lanczos-3, two passes with a uint8 intermediate, 22-bit fixed-point coefficients).
+ * Bit-exact against Pillow.
+ *
+ * boxes_xyxy [n][4] int32: (x0, y0, x1, y1) AFTER Image.crop's rounding (int(round(v)) in Python).
+ * pp_frontend_plan_bytes / pp_frontend_plan_build run on the HOST (no GPU needed): they compute, with
+ * Pillow's own double-precision expressions, the per-box bounds / coefficient tables and the
+ * workgroup table into `plan` (host memory); the caller copies `plan` to the device.
+ * pp_frontend_crop_resize: image uint8 HWC RGB on the device (img_stride = bytes per row), plan_dev =
+ * the device copy of the plan, out [n][3][out_h][out_w] f32 in [0,1] (= f32(u8) * f32(1/255)).
+ * ---------------------------------------------------------------------- */
+long long pp_frontend_plan_bytes(int n_boxes, const int *boxes_xyxy, int out_w, int out_h);   /* < 0: error */
+int pp_frontend_plan_build(int n_boxes, const int *boxes_xyxy, int out_w, int out_h, void *plan,
+                           int *n_blocks_out, long long *lds_bytes_out);
+int pp_frontend_crop_resize(const unsigned char *image, int img_w, int img_h, long long img_stride,
+                            const void *plan_dev, int n_boxes, int n_blocks, long long lds_bytes,
+                            int out_w, int out_h, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

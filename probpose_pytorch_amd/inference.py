@@ -59,11 +59,27 @@ def run_inference(model: ProbPoseModel, codec: Codec, image_tensor: torch.Tensor
     return output, codec.decode(output)
 
 
+def run_inference_on_boxes(model: ProbPoseModel, codec: Codec, frame: torch.Tensor, boxes_xywh):
+    """Whole per-frame path on the GPU: ``frame`` (H, W, 3) uint8 RGB on the device and person boxes
+    [x, y, w, h] -> crops (dataset.py:71-90 semantics, frontend.crop_resize) -> forward -> decode.
+    Returns (raw 5-tuple, decoded predictions, keypoints in FRAME pixels (n, K, 2) float64): the inverse of
+    the keypoint rescale of dataset.py:87-89, ``kpt / input_size * box_wh + box_xy``."""
+    from . import frontend
+    input_size = codec.probmap.input_size
+    crops = frontend.crop_resize(frame, boxes_xywh, input_size)
+    output, preds = run_inference(model, codec, crops)
+    b = np.asarray(boxes_xywh, dtype=np.float64).reshape(-1, 4)
+    kpts = np.asarray(preds[0][0], dtype=np.float64)
+    in_wh = np.asarray(input_size, dtype=np.float64)
+    frame_kpts = kpts / in_wh * b[:, None, 2:4] + b[:, None, 0:2]
+    return output, preds, frame_kpts
+
+
 def load_image(path: Path, input_size) -> torch.Tensor:
     """Reference inference.py:74-82: RGB, LANCZOS resize to input_size [w,h], scale to [0,1]."""
     import PIL.Image
     image = PIL.Image.open(path).convert("RGB").resize(tuple(input_size), PIL.Image.LANCZOS)
-    arr = np.asarray(image, dtype=np.float32) / 255.0
+    arr = np.asarray(image, dtype=np.float32) * np.float32(1.0 / 255.0)   # v2.ToDtype(float32, scale=True)
     return torch.from_numpy(arr).permute(2, 0, 1).unsqueeze(0).contiguous()
 
 

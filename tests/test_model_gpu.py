@@ -198,3 +198,25 @@ def test_full_size_forward_properties_vit_b_bs64(pkg):
     assert dh.mean() < 0.03, dh.mean()
     dec = codec.decode(tuple(f[:2] for f in full))
     assert dec[0][0].shape == (2, 17, 2) and np.isfinite(dec[0][0]).all()
+
+
+def test_run_inference_on_boxes_matches_crop_then_forward(pkg):
+    """frame + boxes -> crops -> forward -> decode == forward of the Pillow-made crops; keypoints mapped
+    back into the frame with the inverse of dataset.py:87-89."""
+    from oracle import frontend_oracle as fo
+    from probpose_pytorch_amd import inference
+    model, hm_size = inference.build_model((192, 256), 17, "vit_s")
+    from probpose_pytorch_amd.synthetic import synthetic_model_state
+    model.load_state_dict(synthetic_model_state((256, 192), 16, 384, 12, 17, 3, (256, 256), seed=0))
+    model = model.to("cuda").eval()
+    codec = pkg["p"].Codec(pkg["p"].ProbMap((192, 256), hm_size, np.array([0.05] * 17)))
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    boxes = [(40.0, 30.0, 200.0, 380.0), (300.5, 100.25, 150.0, 300.0), (-20.0, 200.0, 180.0, 320.0)]
+    out, preds, frame_kpts = inference.run_inference_on_boxes(model, codec, torch.from_numpy(frame).cuda(), boxes)
+    crops = torch.from_numpy(np.stack([fo.scale_box_pil(frame, b, (192, 256)) for b in boxes])).cuda()
+    out2, preds2 = inference.run_inference(model, codec, crops)
+    assert torch.equal(out[0], out2[0])
+    np.testing.assert_array_equal(preds[0][0], preds2[0][0])
+    assert frame_kpts.shape == (3, 17, 2)
+    np.testing.assert_allclose(frame_kpts[1], preds[0][0][1] / [192, 256] * [150.0, 300.0] + [300.5, 100.25])
