@@ -92,20 +92,28 @@ struct FeBox {
   size_t lds;
 };
 
+// Output rows per workgroup: as many as keep >= 1024 workgroups in the launch (4 per CU; fewer, longer
+// workgroups measured slower: 512 -> +17 %), at most 32; fe_prepare lowers it further to fit LDS.
+static int fe_rb_max(int n_boxes, int out_h) {
+  int rb = 32;
+  while (rb > 1 && (long long)n_boxes * ((out_h + rb - 1) / rb) < 1024) rb >>= 1;
+  return rb;
+}
+
 // rows of the temporary image one block of output rows [r0, r0 + rb) reads
 static int fe_span(const std::vector<int> &bv, int out_h, int r0, int rb) {
   const int r1 = std::min(out_h, r0 + rb) - 1;
   return bv[r1 * 2] + bv[r1 * 2 + 1] - bv[r0 * 2];
 }
 
-static int fe_prepare(const int *box, int out_w, int out_h, FeBox &b, bool want_kk) {
+static int fe_prepare(const int *box, int out_w, int out_h, int rb_max, FeBox &b, bool want_kk) {
   const int cw = box[2] - box[0], ch = box[3] - box[1];
   if (cw <= 0 || ch <= 0) return fail("pp_frontend: empty box (%d,%d,%d,%d)", box[0], box[1], box[2], box[3]);
   b.ksh = fe_coeffs(cw, out_w, b.bh, b.kh, want_kk);
   b.ksv = fe_coeffs(ch, out_h, b.bv, b.kv, want_kk);
   // largest block of output rows whose source-row span fits the LDS target (span * out_w RGB bytes)
   b.rb = 0;
-  for (int rb = 16; rb >= 1; rb >>= 1) {
+  for (int rb = rb_max; rb >= 1; rb >>= 1) {
     int span = 0;
     for (int r0 = 0; r0 < out_h; r0 += rb) span = std::max(span, fe_span(b.bv, out_h, r0, rb));
     const size_t lds = (size_t)span * out_w * 3;
@@ -156,14 +164,22 @@ __global__ __launch_bounds__(FE_THREADS) void crop_resize_kernel(const unsigned 
         const int xmin = bh[xx * 2], xmax = bh[xx * 2 + 1];
         const int *k = kh + (size_t)xx * ksh;
         int a0 = 1 << (FE_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+        // one (unaligned) dword load per pixel instead of three byte loads; the 4th byte is ignored.  The
+        // frame's very last pixel is read bytewise so that nothing past the buffer is touched.
+        const bool last_row = iy == img_h - 1;
         for (int x = 0; x < xmax; ++x) {
           const int ix = x0 + xmin + x;
           if (ix >= 0 && ix < img_w) {
             const int kx = k[x];
             const unsigned char *px = row + 3 * ix;
-            a0 += (int)px[0] * kx;
-            a1 += (int)px[1] * kx;
-            a2 += (int)px[2] * kx;
+            unsigned rgb;
+            if (last_row && ix == img_w - 1)
+              rgb = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+            else
+              __builtin_memcpy(&rgb, px, 4);
+            a0 += (int)(rgb & 255u) * kx;
+            a1 += (int)((rgb >> 8) & 255u) * kx;
+            a2 += (int)((rgb >> 16) & 255u) * kx;
           }
         }
         v0 = fe_clip8(a0);
@@ -236,7 +252,7 @@ extern "C" long long pp_frontend_plan_bytes(int n_boxes, const int *boxes_xyxy, 
   size_t words = (size_t)n_boxes * FE_HDR;
   for (int c = 0; c < n_boxes; ++c) {
     FeBox b;
-    if (fe_prepare(boxes_xyxy + 4 * c, out_w, out_h, b, false) != 0) return -1;
+    if (fe_prepare(boxes_xyxy + 4 * c, out_w, out_h, fe_rb_max(n_boxes, out_h), b, false) != 0) return -1;
     words += 2 * (size_t)b.nblocks + b.bh.size() + b.bv.size() + (size_t)out_w * b.ksh + (size_t)out_h * b.ksv;
   }
   return (long long)(words * sizeof(int));
@@ -255,11 +271,12 @@ extern "C" int pp_frontend_plan_build(int n_boxes, const int *boxes_xyxy, int ou
   {
     // the coefficient tables cost ~150 us of libm per box: spread the boxes over host threads
     const int nt = std::max(1, std::min({n_boxes / 2, (int)std::thread::hardware_concurrency(), 16}));
+    const int rb_max = fe_rb_max(n_boxes, out_h);
     std::vector<int> rcs((size_t)n_boxes, 0);
     std::vector<std::string> msgs((size_t)nt);
     auto work = [&](int t) {
       for (int c = t; c < n_boxes; c += nt) {
-        rcs[c] = fe_prepare(boxes_xyxy + 4 * c, out_w, out_h, bx[c], true);
+        rcs[c] = fe_prepare(boxes_xyxy + 4 * c, out_w, out_h, rb_max, bx[c], true);
         if (rcs[c] != 0) msgs[t] = err_buf();     // the error text is thread-local: carry it back
       }
     };

@@ -63,7 +63,7 @@ def test_host_plan_tables_match_pillow_restatement(built_lib):
     """pp_frontend_plan_build runs on the host: its tables must be Pillow's, value for value."""
     boxes = np.array([fo.round_box(b) for b in BOXES], dtype=np.int32)
     host, n_blocks, lds = _plan(built_lib, boxes, SIZE)
-    assert n_blocks >= len(BOXES) * (SIZE[1] // 16) and 0 < lds <= 152 * 1024
+    assert n_blocks >= len(BOXES) and 0 < lds <= 152 * 1024
     for c, box in enumerate(boxes):
         h = host[c * 16:(c + 1) * 16]
         cw, ch = box[2] - box[0], box[3] - box[1]
