@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="no second HIP stream for the aux branches: every kernel runs alone, so a kernel trace of "
+                         "this run shows the kernels' own durations (what roofline.avg_launch_us is measured on)")
     ap.add_argument("--tune-cache", default=None,
                     help="JSON file of per-shape GEMM tile winners: loaded if present, written after the warm-up "
                          "(lets a profiled run start tuned, so its trace holds no tuning launches)")
@@ -180,6 +183,9 @@ def main():
     H, W = cfg["img"]
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     ops.AUTOTUNE = True     # per-shape tile selection measured on this device during the warm-up
+    if args.single_stream:
+        from probpose_pytorch_amd import engine as _engine
+        _engine.SERIALIZE_HEAD = True
     if args.tune_cache and os.path.exists(args.tune_cache):
         ops.load_tune_cache(args.tune_cache)
     model, codec, sd = build(cfg, dtype, device)
@@ -249,7 +255,7 @@ def main():
             local_step()
         torch.cuda.synchronize()
         ops.set_profile(None)
-        engine.SERIALIZE_HEAD = False
+        engine.SERIALIZE_HEAD = bool(args.single_stream)
     agg = {}
     for name, work, s, e, _info in prof:
         a = agg.setdefault(name, [0, 0.0, 0.0])
