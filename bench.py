@@ -37,6 +37,7 @@ CONFIGS = {
 }
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 (MI355X_MICROARCH.md: ~2.5 PF dense)
 PEAK_F32_TFLOPS = 157.3
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 spec figure (the block-scaled MFMA path; the non-scaled fp8 MFMA runs at the bf16 rate)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -144,7 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="vit_b", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true",
@@ -181,7 +182,7 @@ def main():
         cfg["batch"] = args.batch
     B = cfg["batch"]
     H, W = cfg["img"]
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp8": torch.float8_e4m3fn}[args.dtype]
     ops.AUTOTUNE = True     # per-shape tile selection measured on this device during the warm-up
     if args.single_stream:
         from probpose_pytorch_amd import engine as _engine
@@ -268,7 +269,7 @@ def main():
     crops_per_s = B * world * args.steps / elapsed
     if rank == 0:
         g_n, g_flops, g_t = per_step.get("gemm", (0, 0.0, 1.0))
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = {"bf16": PEAK_BF16_TFLOPS, "fp32": PEAK_F32_TFLOPS, "fp8": PEAK_FP8_TFLOPS}[args.dtype]
         achieved = g_flops / g_t / 1e12
         d_n, d_bytes, d_t = per_step.get("decode", (0, 0.0, 1.0))
         a_n, a_flops, a_t = per_step.get("attention", (0, 0.0, 1.0))

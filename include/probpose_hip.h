@@ -31,6 +31,7 @@ extern "C" {
 
 #define PP_F32 0
 #define PP_BF16 1
+#define PP_FP8 2                        /* OCP e4m3 storage (gfx950 fp8 MFMA), fp32 accumulate: pp_gemm / pp_layernorm_fp8 only */
 
 #define PP_MAX_RADIUS 9                 /* heatmap.py:178-179: s<=3.0 -> ceil(3s)<=9 */
 #define PP_MAX_TAPS (2 * PP_MAX_RADIUS + 1)
@@ -49,6 +50,7 @@ extern "C" {
                                            W*diag(gamma), bias holds b + W*beta, colsum[n] = sum_k W'[n,k]; the epilogue
                                            applies out = rstd_m * (acc - mean_m * colsum[n]) + bias[n] with mean/rstd
                                            from stats_in (exactly LN(x) W^T + b in exact arithmetic)                */
+#define PP_EPI_OUT_FP8 512              /* fp8 GEMM only: store e4m3(value * out_scale) instead of bf16 (the next fp8 GEMM's A) */
 #define PP_EPI_HEATMAP 64               /* head.py:526-532: f32 NCHW store of clamp(v / temperature, 0, 1):
                                            C[((r / hm_HW) * hm_K + n) * hm_HW + r % hm_HW], r = output row */
 
@@ -114,7 +116,9 @@ typedef struct pp_gemm_args {
   int rowbias_period;
   int batch;
   long long strideA, strideW, strideC, strideBias, strideRowoff, strideRowmap;
-  int dtype;                    /* PP_F32 | PP_BF16                     */
+  int dtype;                    /* PP_F32 | PP_BF16 | PP_FP8 (A, W e4m3 bytes; C bf16, or f32 / e4m3 by flag;
+                                   K % 128 == 0; colsum = [N] f32 dequantisation scale per output column:
+                                   C = act((A8 W8^T)[m,n] * colsum[n] + bias[n]) (+ residual); tiles 2, 3) */
   int epilogue;                 /* PP_EPI_* flags                       */
   int hm_K, hm_HW;              /* PP_EPI_HEATMAP geometry              */
   float hm_temperature;         /* head.py:107 (0.5)                    */
@@ -124,12 +128,13 @@ typedef struct pp_gemm_args {
                                    column tiles of this launch (N / 192 for tile 3)                     */
   const float *stats_in;        /* PP_EPI_LNFOLD: the producer's stats buffer                           */
   int stats_parts;
-  const float *colsum;          /* PP_EPI_LNFOLD: [N] f32                                               */
+  const float *colsum;          /* PP_EPI_LNFOLD: [N] f32; PP_FP8: [N] f32 column scales (batch stride strideBias) */
   float ln_eps;
   int tile;                     /* 0 = auto (fewest rounds of resident workgroups), 1 = 128x128,
                                    2 = 192x96 (4 waves, 2 LDS stages), 3 = 192x192, 4 = 192x128 (8 waves, 3 stages), 5 = 384x128 (8 waves, 2 stages),
                                    6 = 192x192 wave-specialised (8 MFMA + 4 DMA waves, 3 stages),
                                    7 = 192x384, 8 = 256x256 (8 waves, 2 stages) */
+  float out_scale;              /* PP_EPI_OUT_FP8: 1 / (scale of the fp8 output tensor) */
 } pp_gemm_args;
 int pp_gemm(const pp_gemm_args *args, void *stream);
 
@@ -137,6 +142,9 @@ int pp_gemm(const pp_gemm_args *args, void *stream);
  * x [rows,C] f32 (the fp32 residual stream) -> out [rows,C] in `dtype`. */
 int pp_layernorm(const float *x, const float *gamma, const float *beta, float eps,
                  int rows, int C, void *out, int dtype, void *stream);
+/* Same, output quantised to OCP e4m3: out[r,c] = e4m3(LN(x)[r,c] * inv_scale) (static per-tensor scale). */
+int pp_layernorm_fp8(const float *x, const float *gamma, const float *beta, float eps,
+                     int rows, int C, unsigned char *out, float inv_scale, void *stream);
 
 /* Multi-head self-attention (timm Attention.forward: softmax(q k^T * hd^-1/2) v).
  * qkv [B*N, 3*heads*hd] laid out [3][heads][hd] along the row (timm's

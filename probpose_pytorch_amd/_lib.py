@@ -8,11 +8,11 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libprobpose_hip.so")
 
-PP_F32, PP_BF16 = 0, 1
+PP_F32, PP_BF16, PP_FP8 = 0, 1, 2
 PP_MAX_RADIUS = 9
 PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS, EPI_HEATMAP = 1, 2, 4, 8, 16, 32, 64
-EPI_ROWSTATS, EPI_LNFOLD = 128, 256
+EPI_ROWSTATS, EPI_LNFOLD, EPI_OUT_FP8 = 128, 256, 512
 
 _lock = threading.Lock()
 _lib = None
@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("hm_K", C.c_int), ("hm_HW", C.c_int), ("hm_temperature", C.c_float),
         ("C2", C.c_void_p), ("ldc2", C.c_int), ("stats_out", C.c_void_p), ("stats_in", C.c_void_p),
         ("stats_parts", C.c_int), ("colsum", C.c_void_p), ("ln_eps", C.c_float), ("tile", C.c_int),
+        ("out_scale", C.c_float),
     ]
 
 
@@ -48,6 +49,7 @@ _SIGNATURES = {
     "pp_decode_f32": (C.c_int, [_vp] * 5 + [_i] * 4 + [_vp, _vp] + [_d] * 4 + [_vp] * 9),
     "pp_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "pp_layernorm": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
+    "pp_layernorm_fp8": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _f, _vp]),
     "pp_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

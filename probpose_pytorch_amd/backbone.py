@@ -90,6 +90,11 @@ class VisionTransformer(nn.Module):
     def _plan(self, device):
         return engine.plan_for(self, engine.build_vit_plan, self.compute_dtype, device)
 
+    @property
+    def token_dtype(self) -> torch.dtype:
+        """dtype of forward_tokens' result (fp8 mode keeps tokens, attention and the head in bf16)."""
+        return torch.bfloat16 if self.compute_dtype == torch.float8_e4m3fn else self.compute_dtype
+
     def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) -> device-resident tokens [B*N, C] in the compute dtype (HIP only)."""
         _lib.require_device(x)

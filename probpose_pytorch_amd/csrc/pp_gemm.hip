@@ -82,6 +82,7 @@ struct GemmParams {
   int stats_parts;
   const float *colsum;
   float ln_eps;
+  float out_scale;   // fp8 output: value * out_scale is what gets rounded to e4m3
   int blocked;       // XCD-blocked tile order (large grids) vs plain order
   int lds_epilogue;  // bf16 C tile staged through LDS and stored as whole rows
 };
@@ -126,13 +127,25 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
 }
 template <typename T>
 __device__ __forceinline__ void gelu4(float (&v)[4]) {
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (sizeof(T) <= 2) {
     const f32x2 a = gelu_fast2((f32x2){v[0], v[1]}), b = gelu_fast2((f32x2){v[2], v[3]});
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
   }
+}
+
+// OCP e4m3 (gfx950): 4 floats -> 4 bytes, round-to-nearest-even, saturating at +-448 (NaN stays NaN)
+typedef unsigned char fp8_t;
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
+  b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+  c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f);
+  d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
 }
 
 // WGM x WGN waves per workgroup; STAGES LDS buffers (prefetch distance STAGES-1, counted vmcnt).
@@ -337,6 +350,16 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 #ifdef PP_EXP_SETPRIO
               __builtin_amdgcn_s_setprio(0);
 #endif
+            } else if constexpr (sizeof(T) == 1) {
+              // fp8 (e4m3): the 16-B chunk holds 16 consecutive k = two 8-byte MFMA operands; step h takes half h
+              // of every lane's chunk (k slots 16 * (4s + fq) + 8h .. +7: the same permutation on both operands).
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                      reinterpret_cast<const long *>(&bf[j])[hh], reinterpret_cast<const long *>(&af[i])[hh],
+                      acc[i][j], 0, 0, 0);
             } else {
               // fp32: the chunk holds 4 consecutive k; MFMA step e takes element e of every lane's
               // chunk (k slots 16s + 4*fq + e, the same permutation on both operands).
@@ -398,6 +421,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
           if (n < p.N) {
             const float4 t = *reinterpret_cast<const float4 *>(init_base + rowbase + n);
             c = f32x4{t.x, t.y, t.z, t.w};
+            if constexpr (ES == 1) {   // the fp8 epilogue multiplies the accumulator by colscale[n]: pre-divide
+              const float4 sc = *reinterpret_cast<const float4 *>(p.colsum + (size_t)z * p.strideBias + n);
+              c = f32x4{t.x / sc.x, t.y / sc.y, t.z / sc.z, t.w / sc.w};
+            }
           }
         } else {
 #pragma unroll
@@ -436,6 +463,13 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (VEC && ES == 1) {   // fp8: per-column dequantisation scale (activation scale x weight-row scale)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
+      if (n < p.N) cs4[j] = *reinterpret_cast<const float4 *>(p.colsum + (size_t)z * p.strideBias + n);
+    }
+  }
   if constexpr (VEC && LN == 2) {
     if ((epi & PP_EPI_LNFOLD) && !is_producer) {
 #pragma unroll
@@ -561,7 +595,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
   // operand, so a 16x16 accumulator tile holds C^T: lane (frow, fq) owns output row m = .. + frow and
   // the 4 CONSECUTIVE columns n = .. + 4*fq + e -> 8-byte (bf16) / 16-byte (fp32) vector stores.
   // All additive terms are already in the accumulators: activation, convert, store.
-  char *Cb = p.C + (size_t)z * p.strideC * ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : ES);
+  char *Cb = p.C + (size_t)z * p.strideC *
+                       ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : (ES == 1 ? ((epi & PP_EPI_OUT_FP8) ? 1 : 2) : ES));
   bool stored = false;
   if constexpr (VEC) {
     // Stage the C tile through LDS (the K-loop buffers are dead) and store whole rows: 16 B per lane
@@ -598,6 +633,9 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
               v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
               v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
               v[3] = ln_rstd[i] * (acc[i][j][3] - ln_mean[i] * cs4[j].w) + bias4[j].w;
+            } else if constexpr (sizeof(T) == 1) {
+              v[0] = fmaf(acc[i][j][0], cs4[j].x, bias4[j].x); v[1] = fmaf(acc[i][j][1], cs4[j].y, bias4[j].y);
+              v[2] = fmaf(acc[i][j][2], cs4[j].z, bias4[j].z); v[3] = fmaf(acc[i][j][3], cs4[j].w, bias4[j].w);
             } else {
               v[0] = acc[i][j][0] + bias4[j].x; v[1] = acc[i][j][1] + bias4[j].y;
               v[2] = acc[i][j][2] + bias4[j].z; v[3] = acc[i][j][3] + bias4[j].w;
@@ -619,6 +657,9 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
             char *dst = smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * OES;
             if constexpr (OES == 4) {
               *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else if constexpr (OES == 1) {
+              const float q = p.out_scale;
+              *reinterpret_cast<unsigned *>(dst) = pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q);
             } else {
               uint2 pk;
               pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
@@ -712,6 +753,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     if (p.lds_epilogue) {
       if (sizeof(T) == 4 || (epi & PP_EPI_OUT_F32))
         lds_epilogue(std::integral_constant<int, 4>{});
+      else if (sizeof(T) == 1 && (epi & PP_EPI_OUT_FP8))
+        lds_epilogue(std::integral_constant<int, 1>{});
       else
         lds_epilogue(std::integral_constant<int, 2>{});
       stored = true;
@@ -767,7 +810,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
         const size_t idx = (size_t)r * p.ldc + ne;
         if (epi & PP_EPI_OUT_F32)
           reinterpret_cast<float *>(Cb)[idx] = x;
-        else
+        else if constexpr (sizeof(T) != 1)   // fp8 launches always take the LDS epilogue (checked on the host)
           Store<T>::st(reinterpret_cast<T *>(Cb) + idx, x);
       }
       }
@@ -796,8 +839,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   using namespace pp;
   PP_REQUIRE(a, "pp_gemm: null args");
-  PP_REQUIRE(a->dtype == PP_F32 || a->dtype == PP_BF16, "pp_gemm: bad dtype %d", a->dtype);
-  const int es = a->dtype == PP_BF16 ? 2 : 4;
+  PP_REQUIRE(a->dtype == PP_F32 || a->dtype == PP_BF16 || a->dtype == PP_FP8, "pp_gemm: bad dtype %d", a->dtype);
+  const int es = a->dtype == PP_BF16 ? 2 : (a->dtype == PP_FP8 ? 1 : 4);
   const int bk = ROW_BYTES / es;
   PP_REQUIRE(a->M >= 0 && a->N > 0 && a->Kd > 0, "pp_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->Kd);
   if (a->M == 0 || a->batch == 0) return 0;
@@ -843,6 +886,15 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
   p.C2 = (char *)a->C2; p.ldc2 = a->ldc2; p.stats_out = a->stats_out; p.stats_in = a->stats_in;
   p.stats_parts = a->stats_parts; p.colsum = a->colsum; p.ln_eps = a->ln_eps;
+  p.out_scale = a->out_scale;
+  if (a->dtype == PP_FP8) {
+    PP_REQUIRE(a->colsum && !a->rowoff && !a->out_rowmap && !(a->epilogue & (PP_EPI_ROWSTATS | PP_EPI_LNFOLD | PP_EPI_ROWBIAS | PP_EPI_HEATMAP)),
+               "pp_gemm: fp8 needs colsum = per-column dequantisation scales and a plain (non-gather, non-fused) GEMM");
+    if (a->epilogue & PP_EPI_OUT_FP8)
+      PP_REQUIRE(a->out_scale > 0.f && !(a->epilogue & PP_EPI_OUT_F32), "pp_gemm: PP_EPI_OUT_FP8 needs out_scale > 0");
+  } else {
+    PP_REQUIRE(!(a->epilogue & PP_EPI_OUT_FP8), "pp_gemm: PP_EPI_OUT_FP8 is an fp8-GEMM epilogue");
+  }
   const int batch = a->batch > 0 ? a->batch : 1;
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
@@ -881,7 +933,8 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
   p.blocked = nblk >= 16 ? 1 : 0;
   {
-    const int oes = (a->dtype == PP_F32 || (a->epilogue & PP_EPI_OUT_F32)) ? 4 : 2, per16 = 16 / oes;
+    const int oes = (a->dtype == PP_F32 || (a->epilogue & PP_EPI_OUT_F32)) ? 4 : ((a->epilogue & PP_EPI_OUT_FP8) ? 1 : 2),
+              per16 = 16 / oes;
     p.lds_epilogue = (vec && a->N % per16 == 0 && a->ldc % per16 == 0 && ((uintptr_t)a->C & 15) == 0 &&
                       (a->strideC % per16) == 0)
                          ? 1
@@ -925,7 +978,20 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     p.blocked = nb3 >= 16 ? 1 : 0;
     grid = dim3(p.blocked ? (unsigned)(((nb3 + 7) / 8) * 8 * 8 * 4) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   }
-  if (ln_mode) {
+  if (a->dtype == PP_FP8) {
+    PP_REQUIRE(vec && p.lds_epilogue, "pp_gemm: fp8 needs the vector / LDS epilogue path (aligned N, ldc, C)");
+    if (!(cfg == 2 || cfg == 3)) {
+      PP_REQUIRE(a->tile == 0, "pp_gemm: fp8 is built for tiles 2 and 3, got tile %d", cfg);
+      cfg = 3;
+      p.tiles_m = cdiv(a->M, 192);
+      p.tiles_n = cdiv(a->N, 192);
+      const long long nb3 = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, 4);
+      p.blocked = nb3 >= 16 ? 1 : 0;
+      grid = dim3(p.blocked ? (unsigned)(((nb3 + 7) / 8) * 8 * 8 * 4) : (unsigned)(p.tiles_m * p.tiles_n), batch);
+    }
+    if (cfg == 2) PP_LAUNCH_GEMM_V(fp8_t, 192, 96, 2, 2, 2, false, true);
+    else PP_LAUNCH_GEMM_V(fp8_t, 192, 192, 2, 4, 3, false, true);
+  } else if (ln_mode) {
     // LayerNorm-fused instantiations exist for the plain (non-gather) 192x192 tile, and for consumers the 192x96 tile
     PP_REQUIRE(!gather && vec && (cfg == 3 || (cfg == 2 && ln_mode == 2)),
                "pp_gemm: LayerNorm fusion is built for tile 3 (and tile 2 on the consumer side), got tile %d", cfg);

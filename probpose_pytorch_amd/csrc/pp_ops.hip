@@ -10,11 +10,21 @@ namespace pp {
 // LayerNorm: one wave per row, the row held in registers (C <= 2048) so HBM/L2
 // is read once; fp32 statistics (two-pass, like torch's RowwiseMoments result).
 // ---------------------------------------------------------------------------
+// T = unsigned char: the output is OCP e4m3 of value * qscale (static per-tensor scale), saturating at 448.
+__device__ __forceinline__ unsigned ln_pack_fp8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
+  b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+  c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f);
+  d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float eps,
-                                                        int rows, int C, T *__restrict__ out) {
+                                                        int rows, int C, T *__restrict__ out, float qscale = 1.0f) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -53,6 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                     o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
         if constexpr (sizeof(T) == 4) {
           *reinterpret_cast<float4 *>(orow + c) = make_float4(o0, o1, o2, o3);
+        } else if constexpr (sizeof(T) == 1) {
+          *reinterpret_cast<unsigned *>(orow + c) = ln_pack_fp8x4(o0 * qscale, o1 * qscale, o2 * qscale, o3 * qscale);
         } else {
           ushort4 pk;
           pk.x = f32_to_bf16(o0); pk.y = f32_to_bf16(o1); pk.z = f32_to_bf16(o2); pk.w = f32_to_bf16(o3);
@@ -71,7 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     q += d * d;
   }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-  for (int c = lane; c < C; c += 64) Store<T>::st(orow + c, (xr[c] - mean) * rstd * gamma[c] + beta[c]);
+  if constexpr (sizeof(T) != 1)   // fp8 output is launched for C % 4 == 0, C <= 2048 only (checked on the host)
+    for (int c = lane; c < C; c += 64) Store<T>::st(orow + c, (xr[c] - mean) * rstd * gamma[c] + beta[c]);
 }
 
 // ---------------------------------------------------------------------------
@@ -388,6 +401,18 @@ extern "C" int pp_layernorm(const float *x, const float *gamma, const float *bet
   else
     return fail("pp_layernorm: bad dtype %d", dtype);
   PP_CHECK_LAUNCH("layernorm_kernel");
+  return 0;
+}
+
+extern "C" int pp_layernorm_fp8(const float *x, const float *gamma, const float *beta, float eps, int rows, int C,
+                                unsigned char *out, float inv_scale, void *stream) {
+  PP_REQUIRE(rows >= 0 && C > 0 && (C & 3) == 0 && C <= 2048, "pp_layernorm_fp8: C must be a multiple of 4, <= 2048");
+  PP_REQUIRE(inv_scale > 0.f, "pp_layernorm_fp8: inv_scale must be positive");
+  if (rows == 0) return 0;
+  PP_REQUIRE(x && gamma && beta && out, "pp_layernorm_fp8: null pointer");
+  hipLaunchKernelGGL(layernorm_kernel<unsigned char>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                     beta, eps, rows, C, out, inv_scale);
+  PP_CHECK_LAUNCH("layernorm_kernel<fp8>");
   return 0;
 }
 

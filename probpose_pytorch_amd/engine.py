@@ -77,8 +77,8 @@ class _Workspace:
 # ViT backbone
 # ---------------------------------------------------------------------------
 class VitPlan:
-    def __init__(self, vit, dtype: torch.dtype, device):
-        self.dtype, self.device = dtype, device
+    def __init__(self, vit, dtype: torch.dtype, device, fp8: bool = False):
+        self.dtype, self.device, self.fp8 = dtype, device, fp8
         pe = vit.patch_embed
         self.patch = int(pe.patch_size[0])
         self.img_size = tuple(pe.img_size)
@@ -101,7 +101,15 @@ class VitPlan:
                 fc1_w=_dev(blk.mlp.fc1.weight, device, dtype), fc1_b=_dev(blk.mlp.fc1.bias, device, torch.float32),
                 fc2_w=_dev(blk.mlp.fc2.weight, device, dtype), fc2_b=_dev(blk.mlp.fc2.bias, device, torch.float32),
             ))
-        self.fuse_ln = bool(FUSE_LAYERNORM and dtype == torch.bfloat16 and len(self.blocks) > 0)
+        if fp8:
+            # qkv / fc1 / fc2 on fp8 MFMA: e4m3 weights, one scale per output channel (row of W); the activation
+            # scales are static per tensor and come from a calibration pass on the first batch (_calibrate_fp8)
+            for b, blk in zip(self.blocks, vit.blocks):
+                for name, lin in (("qkv", blk.attn.qkv), ("fc1", blk.mlp.fc1), ("fc2", blk.mlp.fc2)):
+                    w8, sw = ops.quantize_rows_fp8(lin.weight.detach().to(device))
+                    b[name + "_w8"], b[name + "_sw"] = w8, sw
+            self.fp8_calibrated = False
+        self.fuse_ln = bool(FUSE_LAYERNORM and not fp8 and dtype == torch.bfloat16 and len(self.blocks) > 0)
         if self.fuse_ln:
             for b, blk in zip(self.blocks, vit.blocks):
                 for name, lin, nw, nb in (("qkv", blk.attn.qkv, blk.norm1.weight, blk.norm1.bias),
@@ -139,6 +147,16 @@ class VitPlan:
             ops.patchify(x, a0, self.patch)
             return self._forward_tokens_fused(B, M, a0, xres, qkv, ao, hid, feats)
         bufs = (a0, xres, h, qkv, ao, hid, feats)
+        if self.fp8:
+            if not self.fp8_calibrated:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("fp8 mode calibrates its activation scales on the first batch: run one eager "
+                                       "forward before capturing a graph")
+                self._calibrate_fp8(x, B, bufs)
+            h8 = g("h8", (M, C), ops.FP8, dev)
+            hid8 = g("hid8", (M, self.hidden), ops.FP8, dev)
+            self._run_chain_fp8(x, B, (a0, xres, h8, qkv, ao, hid8, feats))
+            return feats
         if DUAL_CHAIN and not SERIALIZE_HEAD and B % 2 == 0 and B >= DUAL_CHAIN_MIN_BATCH:
             # Two half-batches as two independent kernel chains on two HIP streams (row slices of the same
             # buffers, same weights).  Every kernel of the path is bulk-synchronous: all its workgroups
@@ -183,6 +201,53 @@ class VitPlan:
         ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
 
 
+def _vit_calibrate_fp8(self, x, B, bufs, margin: float = 1.0):
+    """One bf16 pass over the batch recording amax of the three quantised activations of every block
+    (LN1 output, LN2 output, GELU output) -> static scales amax / 448, and the per-column dequantisation
+    vectors (activation scale x weight-row scale) of the three fp8 GEMMs."""
+    a0, xres, h, qkv, ao, hid, feats = bufs
+    C, N = self.C, self.N
+    M = B * N
+    ops.patchify(x, a0, self.patch)
+    ops.gemm(a0, self.pe_w, xres, M=M, N=C, Kd=a0.shape[1], lda=a0.shape[1], ldw=a0.shape[1], ldc=C,
+             bias=self.pe_b, rowbias=self.pos, rowbias_period=N, epilogue=EPI_OUT_F32)
+    amax = lambda t: max(float(t.float().abs().max()), 1e-6) * margin / ops.FP8_MAX
+    for b in self.blocks:
+        ops.layernorm(xres, b["n1w"], b["n1b"], b["eps1"], h)
+        b["s_h1"] = amax(h)
+        ops.linear(h, b["qkv_w"], b["qkv_b"], out=qkv)
+        ops.attention(qkv, ao, B, N, self.heads, self.hd)
+        ops.linear(ao, b["proj_w"], b["proj_b"], out=xres, residual=xres)
+        ops.layernorm(xres, b["n2w"], b["n2b"], b["eps2"], h)
+        b["s_h2"] = amax(h)
+        ops.linear(h, b["fc1_w"], b["fc1_b"], out=hid, epilogue=EPI_GELU)
+        b["s_hid"] = amax(hid)
+        ops.linear(hid, b["fc2_w"], b["fc2_b"], out=xres, residual=xres)
+        b["qkv_cs"] = (b["qkv_sw"] * b["s_h1"]).contiguous()
+        b["fc1_cs"] = (b["fc1_sw"] * b["s_h2"]).contiguous()
+        b["fc2_cs"] = (b["fc2_sw"] * b["s_hid"]).contiguous()
+    self.fp8_calibrated = True
+
+
+def _vit_run_chain_fp8(self, x, B, bufs):
+    a0, xres, h8, qkv, ao, hid8, feats = bufs
+    C, N = self.C, self.N
+    M = B * N
+    ops.patchify(x, a0, self.patch)
+    ops.gemm(a0, self.pe_w, xres, M=M, N=C, Kd=a0.shape[1], lda=a0.shape[1], ldw=a0.shape[1], ldc=C,
+             bias=self.pe_b, rowbias=self.pos, rowbias_period=N, epilogue=EPI_OUT_F32)
+    for b in self.blocks:
+        ops.layernorm(xres, b["n1w"], b["n1b"], b["eps1"], h8, out_scale=b["s_h1"])
+        ops.linear(h8, b["qkv_w8"], b["qkv_b"], out=qkv, colscale=b["qkv_cs"])
+        ops.attention(qkv, ao, B, N, self.heads, self.hd)
+        ops.linear(ao, b["proj_w"], b["proj_b"], out=xres, residual=xres)          # bf16: smallest GEMM of the block
+        ops.layernorm(xres, b["n2w"], b["n2b"], b["eps2"], h8, out_scale=b["s_h2"])
+        ops.linear(h8, b["fc1_w8"], b["fc1_b"], out=hid8, epilogue=EPI_GELU, colscale=b["fc1_cs"],
+                   out_scale=b["s_hid"])
+        ops.linear(hid8, b["fc2_w8"], b["fc2_b"], out=xres, residual=xres, colscale=b["fc2_cs"])
+    ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
+
+
 def _vit_forward_tokens_fused(self, B, M, a0, xres, qkv, ao, hid, feats):
     """bf16 forward with the in-block LayerNorms folded into the GEMM epilogues (see FUSE_LAYERNORM)."""
     dev, dt, C, N = self.device, self.dtype, self.C, self.N
@@ -212,7 +277,13 @@ def _vit_forward_tokens_fused(self, B, M, a0, xres, qkv, ao, hid, feats):
 VitPlan._forward_tokens_fused = _vit_forward_tokens_fused
 
 
+VitPlan._calibrate_fp8 = _vit_calibrate_fp8
+VitPlan._run_chain_fp8 = _vit_run_chain_fp8
+
+
 def build_vit_plan(vit, dtype, device):
+    if dtype == ops.FP8:
+        return VitPlan(vit, torch.bfloat16, device, fp8=True)
     return VitPlan(vit, dtype, device)
 
 

@@ -20,14 +20,16 @@ class ProbPoseModel(nn.Module):
         self.head = head
 
     def set_compute_dtype(self, dtype: torch.dtype):
-        """torch.float32 (exact-fp32 MFMA, parity mode; default) or torch.bfloat16."""
+        """torch.float32 (exact-fp32 MFMA, parity mode; default), torch.bfloat16, or torch.float8_e4m3fn:
+        the ViT's qkv / fc1 / fc2 GEMMs on fp8 MFMA (e4m3 weights with per-output-channel scales, e4m3
+        activations with static per-tensor scales calibrated on the first batch), everything else bf16."""
         self.backbone.set_compute_dtype(dtype)
-        self.head.set_compute_dtype(dtype)
+        self.head.set_compute_dtype(torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype)
         return self
 
     def forward(self, x: Tensor):
         if isinstance(self.backbone, ScratchViTBackbone) and isinstance(self.head, ProbMapHead) \
-                and self.backbone.model.compute_dtype == self.head.compute_dtype:
+                and self.backbone.model.token_dtype == self.head.compute_dtype:
             B, _, height, width = x.shape
             tokens = self.backbone.model.forward_tokens(x)
             gh, gw = self.backbone.model.patch_embed.dynamic_feat_size((height, width))

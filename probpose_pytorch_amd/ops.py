@@ -11,10 +11,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_LNFOLD, EPI_OUT_F32, EPI_RELU, EPI_RESIDUAL,  # noqa: F401
-                   EPI_ROWBIAS, EPI_ROWSTATS, PP_BF16, PP_F32)
+from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_LNFOLD, EPI_OUT_F32, EPI_OUT_FP8, EPI_RELU,  # noqa: F401
+                   EPI_RESIDUAL, EPI_ROWBIAS, EPI_ROWSTATS, PP_BF16, PP_F32, PP_FP8)
 
-_DT = {torch.float32: PP_F32, torch.bfloat16: PP_BF16}
+FP8 = torch.float8_e4m3fn          # OCP e4m3: what gfx950's fp8 MFMA and conversions use
+FP8_MAX = 448.0
+_DT = {torch.float32: PP_F32, torch.bfloat16: PP_BF16, FP8: PP_FP8}
 
 
 _PROFILE = None  # bench.py's kernel-level timing hook: list of (name, work, start_event, end_event)
@@ -41,7 +43,7 @@ def dtype_code(dt: torch.dtype) -> int:
     try:
         return _DT[dt]
     except KeyError:
-        raise TypeError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dt}") from None
+        raise TypeError(f"compute dtype must be torch.float32, torch.bfloat16 or torch.float8_e4m3fn, got {dt}") from None
 
 
 def _p(t):
@@ -106,8 +108,10 @@ def _tune(a, key, out, residual):
 def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
          strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0,
-         ln_producer=None, ln_consumer=None):
-    """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h."""
+         ln_producer=None, ln_consumer=None, colscale=None, out_scale=None):
+    """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h.
+    fp8 (A, W torch.float8_e4m3fn): ``colscale`` [N] f32 = activation scale x weight-row scale; ``out`` may be
+    bf16, f32 (with residual) or fp8 (then ``out_scale`` = the scale of the output tensor)."""
     a = _lib.GemmArgs()
     a.A, a.W, a.C = _p(A), _p(W), _p(out)
     a.bias, a.residual, a.rowbias = _p(bias), _p(residual), _p(rowbias)
@@ -139,6 +143,15 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         stats, colsum, eps = ln_consumer
         epilogue |= EPI_LNFOLD
         a.stats_in, a.stats_parts, a.colsum, a.ln_eps = _p(stats), stats.shape[1], _p(colsum), float(eps)
+    if a.dtype == PP_FP8:
+        if colscale is None or A.dtype != FP8:
+            raise TypeError("fp8 GEMM: A and W must both be float8_e4m3fn and colscale [N] f32 is required")
+        a.colsum = _p(colscale)
+        if out.dtype == FP8:
+            epilogue |= EPI_OUT_FP8
+            a.out_scale = 1.0 / float(out_scale)
+        elif out.dtype == torch.float32:
+            epilogue |= EPI_OUT_F32
     a.epilogue = epilogue
     a.tile = tile
     if tile == 0 and AUTOTUNE and M * N * Kd >= (1 << 24):
@@ -154,21 +167,36 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
     return out
 
 
-def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=None, tile=0):
+def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=None, tile=0, colscale=None,
+           out_scale=None):
     """x [M,K] @ w[N,K]^T (+bias, activation / fp32 residual add)."""
     M, Kd = x.shape
     N = w.shape[0]
     if residual is not None or out_dtype == torch.float32:
         epilogue |= EPI_OUT_F32
     if out is None:
-        dt = torch.float32 if (epilogue & EPI_OUT_F32) else w.dtype
+        dt = torch.float32 if (epilogue & EPI_OUT_F32) else (out_dtype or (torch.bfloat16 if w.dtype == FP8 else w.dtype))
         out = torch.empty((M, N), dtype=dt, device=x.device)
     return gemm(x, w, out, M=M, N=N, Kd=Kd, lda=x.stride(0), ldw=w.stride(0), ldc=out.stride(0),
-                bias=bias, residual=residual, epilogue=epilogue, tile=tile)
+                bias=bias, residual=residual, epilogue=epilogue, tile=tile, colscale=colscale, out_scale=out_scale)
 
 
-def layernorm(x, gamma, beta, eps, out):
+def quantize_rows_fp8(w: torch.Tensor):
+    """[N,K] float weights -> (float8_e4m3fn [N,K], scale [N] f32): per-output-channel symmetric scaling,
+    amax -> 448, round-to-nearest-even (torch's cast)."""
+    w32 = w.detach().float()
+    scale = (w32.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX).contiguous()
+    return (w32 / scale[:, None]).to(FP8).contiguous(), scale
+
+
+def layernorm(x, gamma, beta, eps, out, out_scale=None):
     rows, Cc = x.shape
+    if out.dtype == FP8:     # static per-tensor scale: out = e4m3(LN(x) / out_scale)
+        rc = _timed("layernorm", float(rows * Cc * 5),
+                    lambda: _lib.lib().pp_layernorm_fp8(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(out),
+                                                        1.0 / float(out_scale), _lib.stream_ptr()))
+        _lib.check(rc, "pp_layernorm_fp8")
+        return out
     rc = _timed("layernorm", float(rows * Cc * (4 + out.element_size())),
                 lambda: _lib.lib().pp_layernorm(_p(x), _p(gamma), _p(beta), float(eps), rows, Cc, _p(out),
                                                 dtype_code(out.dtype), _lib.stream_ptr()))

@@ -296,3 +296,81 @@ def test_bad_arguments_raise(ops):
         ops.attention(torch.zeros((4, 3 * 48), device="cuda"), torch.zeros((4, 48), device="cuda"), 1, 4, 1, 48)
     with pytest.raises(TypeError):
         ops.linear(A.half(), W.half())
+
+
+# ---------------------------------------------------------------------------
+# fp8 (OCP e4m3) GEMM / LayerNorm: BASELINE config 5.  Reference = float64 product of the SAME e4m3
+# operands (torch's casts), so only the fp32 accumulation order and the output rounding differ.
+# ---------------------------------------------------------------------------
+def _fp8_case(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn((M, K), generator=g)
+    w = torch.randn((N, K), generator=g) * K ** -0.5
+    sa = float(a.abs().max()) / 448.0
+    a8 = (a / sa).to(torch.float8_e4m3fn)
+    from probpose_pytorch_amd import ops as _ops
+    w8, sw = _ops.quantize_rows_fp8(w)
+    bias = torch.randn((N,), generator=g)
+    cs = (sa * sw).contiguous()
+    ref = (a8.double() @ w8.double().T) * cs.double()[None, :] + bias.double()[None, :]
+    return a8.cuda(), w8.cuda(), cs.cuda(), bias.cuda(), ref
+
+
+@pytest.mark.parametrize("tile", [0, 2, 3])
+@pytest.mark.parametrize("M,N,K", [(192, 192, 128), (500, 384, 768), (1000, 96, 256), (77, 776, 384)])
+def test_gemm_fp8_bf16_out(ops, M, N, K, tile):
+    a8, w8, cs, bias, ref = _fp8_case(M, N, K, 11)
+    out = ops.linear(a8, w8, bias, colscale=cs, tile=tile)
+    assert out.dtype == torch.bfloat16
+    torch.testing.assert_close(out.double().cpu(), ref, rtol=2 ** -8, atol=1e-3)
+
+
+def test_gemm_fp8_gelu_fp8_out_and_residual(ops):
+    M, N, K = 384, 768, 256
+    a8, w8, cs, bias, ref = _fp8_case(M, N, K, 12)
+    # fc1-style: GELU, output quantised to e4m3 with a static scale
+    act = F.gelu(ref)
+    so = float(act.abs().max()) / 448.0
+    out8 = torch.empty((M, N), dtype=torch.float8_e4m3fn, device="cuda")
+    ops.linear(a8, w8, bias, out=out8, epilogue=ops.EPI_GELU, colscale=cs, out_scale=so)
+    got = out8.float().cpu().double() * so
+    want8 = (act / so).float().to(torch.float8_e4m3fn).double() * so
+    # equal up to one e4m3 step (2^-3 relative) where fp32-vs-fp64 accumulation lands across a rounding boundary
+    err = (got - want8).abs()
+    assert float((err > 0).double().mean()) < 0.02, "more than 2 % of the outputs differ from the f64 rounding"
+    assert bool((err <= act.abs() * 2 ** -3 + so * 2 ** -9).all())
+    # fc2-style: fp32 residual stream updated in place
+    res = torch.randn((M, N), generator=torch.Generator().manual_seed(5)).cuda()
+    want = res.double().cpu() + ref
+    ops.linear(a8, w8, bias, out=res, residual=res, colscale=cs)
+    # fp32 accumulation of e4m3 products: partial sums reach ~5e7 (ulp 4) before the 5e-6 dequantisation scale
+    torch.testing.assert_close(res.double().cpu(), want, rtol=1e-5, atol=1e-3)
+
+
+def test_gemm_fp8_argument_checks(ops):
+    a8, w8, cs, bias, _ = _fp8_case(192, 192, 128, 1)
+    with pytest.raises(TypeError):
+        ops.linear(a8, w8, bias)                      # no column scales
+    with pytest.raises(ops._lib.HipExtensionError):
+        ops.linear(a8[:, :64], w8[:, :64], bias, colscale=cs)     # K must be a multiple of 128
+    with pytest.raises(ops._lib.HipExtensionError):
+        ops.linear(a8, w8, bias, colscale=cs, tile=5)
+
+
+def test_layernorm_fp8(ops):
+    rows, C = 300, 1024
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn((rows, C), generator=g) * 3 + 1).cuda()
+    gam, bet = torch.randn((C,), generator=g).cuda(), torch.randn((C,), generator=g).cuda()
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-6).cpu()
+    scale = float(ref.abs().max()) / 448.0
+    out = torch.empty((rows, C), dtype=torch.float8_e4m3fn, device="cuda")
+    ops.layernorm(x, gam, bet, 1e-6, out, out_scale=scale)
+    got = out.float().cpu().double() * scale
+    want = (ref / scale).float().to(torch.float8_e4m3fn).double() * scale
+    err = (got - want).abs()
+    assert float((err > 0).double().mean()) < 0.01
+    assert bool((err <= ref.abs() * 2 ** -3 + scale * 2 ** -9).all())
+    # saturation instead of NaN: values beyond the scale clamp to +-448
+    ops.layernorm(x, gam, bet, 1e-6, out, out_scale=scale / 4)
+    assert torch.isfinite(out.float()).all() and float(out.float().abs().max()) == 448.0
