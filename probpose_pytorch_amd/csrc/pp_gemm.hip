@@ -309,6 +309,52 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     constexpr bool DO_STAGE = decltype(do_stage_c)::value;
     const char *ldsA = smem + buf * STAGE_BYTES;
     const char *ldsB = ldsA + A_BYTES;
+    if constexpr (ES == 1) {
+      // fp8: one block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit scales 2^0) consumes the whole 128-deep
+      // K-tile of a 16x16 output tile at twice the bf16 rate.  Lane (row, fq) supplies its two 16-B chunks
+      // 4*0 + fq and 4*1 + fq = 32 k values; the k order inside the tile is the same permutation on both operands.
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      uint4 a8[TM][2], b8[TN][2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ra = wm * (BM / WGM) + i * 16 + frow;
+          a8[i][hh] = *reinterpret_cast<const uint4 *>(ldsA + ra * ROW_BYTES + (((4 * hh + fq) ^ (ra & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int rb = wn * (BN / WGN) + j * 16 + frow;
+          b8[j][hh] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * hh + fq) ^ (rb & 7)) << 4));
+        }
+      }
+      constexpr int UNIT = 0x7f7f7f7f;   // E8M0 exponent 127 = 2^0 in every byte
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+          constexpr int i = I;
+          if constexpr (DO_STAGE) {
+            [&]<int... Q>(std::integer_sequence<int, Q...>) {
+              ([&] {
+                if constexpr ((Q * TM) / PIECES == i) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  stage_piece(std::integral_constant<int, Q>{});
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }(), ...);
+            }(std::make_integer_sequence<int, PIECES>{});
+          }
+          const i32x8 av = {(int)a8[i][0].x, (int)a8[i][0].y, (int)a8[i][0].z, (int)a8[i][0].w,
+                            (int)a8[i][1].x, (int)a8[i][1].y, (int)a8[i][1].z, (int)a8[i][1].w};
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const i32x8 bv = {(int)b8[j][0].x, (int)b8[j][0].y, (int)b8[j][0].z, (int)b8[j][0].w,
+                              (int)b8[j][1].x, (int)b8[j][1].y, (int)b8[j][1].z, (int)b8[j][1].w};
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bv, av, acc[i][j], 0, 0, 0, UNIT, 0, UNIT);
+          }
+        }(), ...);
+      }(std::make_integer_sequence<int, TM>{});
+      return;
+    }
     [&]<int... S>(std::integer_sequence<int, S...>) {
       ([&] {
         constexpr int s = S;
