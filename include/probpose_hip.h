@@ -133,7 +133,7 @@ typedef struct pp_gemm_args {
   int tile;                     /* 0 = auto (fewest rounds of resident workgroups), 1 = 128x128,
                                    2 = 192x96 (4 waves, 2 LDS stages), 3 = 192x192, 4 = 192x128 (8 waves, 3 stages), 5 = 384x128 (8 waves, 2 stages),
                                    6 = 192x192 wave-specialised (8 MFMA + 4 DMA waves, 3 stages),
-                                   7 = 192x384, 8 = 256x256 (8 waves, 2 stages) */
+                                   7 = 192x384, 8 = 256x256, 9 = 192x256 (8 waves, 2 stages; bf16) */
   float out_scale;              /* PP_EPI_OUT_FP8: 1 / (scale of the fp8 output tensor) */
 } pp_gemm_args;
 int pp_gemm(const pp_gemm_args *args, void *stream);

@@ -947,9 +947,9 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages),
   // 5 = 384x128 (8 waves, 2 stages; the N = 256 deconvolution layers), 6 = 192x192 wave-specialised
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
-  // 8 = 256x256 (8 waves, 2 stages).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
+  // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 8, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 9, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -972,7 +972,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : (cfg == 7 ? 384 : (cfg == 8 ? 256 : 128))));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   const int rn_ = (cfg >= 3) ? 4 : 8;
@@ -1066,6 +1066,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 5) PP_LAUNCH_GEMM(bf16_t, 384, 128, 2, 4, 2);
     else if (cfg == 7) PP_LAUNCH_GEMM(bf16_t, 192, 384, 2, 4, 2);
     else if (cfg == 8) PP_LAUNCH_GEMM(bf16_t, 256, 256, 2, 4, 2);
+    else if (cfg == 9) PP_LAUNCH_GEMM(bf16_t, 192, 256, 2, 4, 2);
     else if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
   } else {
@@ -1075,7 +1076,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 4) PP_LAUNCH_GEMM(float, 192, 128, 2, 4, 3);
     else if (cfg == 5) PP_LAUNCH_GEMM(float, 384, 128, 2, 4, 2);
     else if (cfg == 7) PP_LAUNCH_GEMM(float, 192, 384, 2, 4, 2);
-    else if (cfg == 8) return fail("pp_gemm: the 256x256 tile is built for bf16 only (fp32 fragments do not fit the register file)");
+    else if (cfg == 8 || cfg == 9) return fail("pp_gemm: the 256-wide tiles are built for bf16 only (fp32 fragments do not fit the register file)");
     else if (gather) PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, false, true, 4);
   }

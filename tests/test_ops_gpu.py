@@ -36,12 +36,12 @@ def _tol(dtype, out_dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 768, 768), (300, 200, 128), (1, 17, 256), (257, 129, 64),
                                    (384, 2304, 768), (192, 96, 64), (193, 97, 128), (400, 400, 3072)])
 def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
-    if tile == 8 and dtype == torch.float32:
-        pytest.skip("256x256 tile is bf16-only")
+    if tile in (8, 9) and dtype == torch.float32:
+        pytest.skip("the 256-wide tiles are bf16-only")
     A, W = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, K ** -0.5)
     b = _rand((N,), torch.float32, 3)
     out = ops.linear(A, W, b, tile=tile)
@@ -120,12 +120,12 @@ def _check_branches(x, Wp, bias, out, B, h, w, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("k", [4, 3, 2])
 def test_gemm_deconv_parities_scatter(ops, dtype, k, tile):
     from probpose_pytorch_amd import pack
-    if tile == 8 and dtype == torch.float32:
-        pytest.skip("256x256 tile is bf16-only")
+    if tile in (8, 9) and dtype == torch.float32:
+        pytest.skip("the 256-wide tiles are bf16-only")
     B, h, w, Cin, Cout = 2, 8, 6, 64, 128
     x = _rand((B * h * w, Cin), dtype, 1)
     wt = _rand((Cin, Cout, k, k), torch.float32, 2, (4 * Cin) ** -0.5)

@@ -10,6 +10,7 @@ import bench
 from probpose_pytorch_amd import engine, ops
 
 engine.SERIALIZE_HEAD = True
+ops.AUTOTUNE = True
 from probpose_pytorch_amd.synthetic import synthetic_crops
 
 cfg = dict(bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "vit_b"])
