@@ -2,6 +2,8 @@
 // LayerNorm, patch im2col, max-pool+ReLU, the aux-branch 1x1 tail, layout
 // transposes, and the exact-fp32 VALU attention used in parity mode (the bf16
 // MFMA attention lives in pp_attention.hip).
+#include <algorithm>
+
 #include "pp_common.h"
 
 namespace pp {
@@ -236,6 +238,89 @@ __global__ __launch_bounds__(256) void final_heatmap_kernel(const T *__restrict_
         if (k < K) out[((size_t)b * K + k) * HW + hw] = fminf(fmaxf((acc[u] + bias[k]) / temperature, 0.f), 1.f);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 form on the matrix cores (HW % 16 == 0, Cin % 32 == 0): the VALU form above spends ~50 us of its 77 us
+// on bf16 -> f32 conversions and FMAs for ViT-B bs 64; here a wave takes 16 pixel rows at a time, loads their
+// Cin values straight from HBM into MFMA A fragments (lane (row, kq): 16 B at k = 32 s + 8 kq; the next
+// tile's loads are issued before the current tile's MFMAs), multiplies by W^T held in LDS (rows padded by 16 B
+// against bank conflicts) and stores float4 = 4 consecutive pixels of one keypoint map: the accumulator of
+// v_mfma_f32_16x16x32_bf16(A = pixels, B = maps) holds rows 4 (lane >> 4) + r of column lane & 15.
+// ---------------------------------------------------------------------------
+typedef __bf16 fh_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float fh_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int FHM_MAXKS = 16;   // Cin <= 512
+
+template <int NT>
+__global__ __launch_bounds__(256) void final_heatmap_mfma_kernel(const bf16_t *__restrict__ x,
+                                                                 const bf16_t *__restrict__ w,
+                                                                 const float *__restrict__ bias,
+                                                                 float *__restrict__ out, int tiles, int HW, int Cin,
+                                                                 int K, float temperature) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // W^T: [NT * 16][Cin * 2 + 16] bytes
+  const int wstride = Cin * 2 + 16;
+  const int chunks = Cin / 8, ks = Cin / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < NT * 16 * chunks; i += 256) {
+    const int n = i / chunks, c = i - n * chunks;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < K) v = *reinterpret_cast<const uint4 *>(w + (size_t)n * Cin + c * 8);
+    *reinterpret_cast<uint4 *>(smem + n * wstride + c * 16) = v;
+  }
+  __syncthreads();
+  const int row = lane & 15, kq = lane >> 4;
+  const int wave = blockIdx.x * 4 + (tid >> 6), nwaves = gridDim.x * 4;
+  float bn[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bn[j] = (j * 16 + row < K) ? bias[j * 16 + row] : 0.f;
+  uint4 cur[FHM_MAXKS], nxt[FHM_MAXKS];
+  int tile = wave;
+  if (tile < tiles) {
+    const bf16_t *xr = x + ((size_t)tile * 16 + row) * Cin + kq * 8;
+#pragma unroll
+    for (int s_ = 0; s_ < FHM_MAXKS; ++s_)
+      if (s_ < ks) cur[s_] = *reinterpret_cast<const uint4 *>(xr + s_ * 32);
+  }
+  for (; tile < tiles; tile += nwaves) {
+    const int nt = tile + nwaves;
+    if (nt < tiles) {
+      const bf16_t *xr = x + ((size_t)nt * 16 + row) * Cin + kq * 8;
+#pragma unroll
+      for (int s_ = 0; s_ < FHM_MAXKS; ++s_)
+        if (s_ < ks) nxt[s_] = *reinterpret_cast<const uint4 *>(xr + s_ * 32);
+    }
+    fh_f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = fh_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < FHM_MAXKS; ++s_) {
+      if (s_ < ks) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const uint4 wf = *reinterpret_cast<const uint4 *>(smem + (j * 16 + row) * wstride + (4 * s_ + kq) * 16);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const fh_bf16x8 *>(&cur[s_]),
+                                                           *reinterpret_cast<const fh_bf16x8 *>(&wf), acc[j], 0, 0, 0);
+        }
+      }
+    }
+    const long long m0 = (long long)tile * 16;           // 16 | HW: the tile lies inside one crop
+    const int b = (int)(m0 / HW), hw = (int)(m0 - (long long)b * HW) + 4 * kq;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = j * 16 + row;
+      if (n < K) {
+        float4 o;
+        o.x = fminf(fmaxf((acc[j][0] + bn[j]) / temperature, 0.f), 1.f);
+        o.y = fminf(fmaxf((acc[j][1] + bn[j]) / temperature, 0.f), 1.f);
+        o.z = fminf(fmaxf((acc[j][2] + bn[j]) / temperature, 0.f), 1.f);
+        o.w = fminf(fmaxf((acc[j][3] + bn[j]) / temperature, 0.f), 1.f);
+        *reinterpret_cast<float4 *>(out + ((size_t)b * K + n) * HW + hw) = o;
+      }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < FHM_MAXKS; ++s_) cur[s_] = nxt[s_];
   }
 }
 
@@ -487,6 +572,27 @@ extern "C" int pp_final_heatmap(const void *x, const void *w, const float *bias,
   PP_REQUIRE(Cin % vec == 0, "pp_final_heatmap: Cin=%d must be a multiple of %d", Cin, vec);
   const long long M = (long long)B * HW;
   PP_REQUIRE(M < (1ll << 31), "pp_final_heatmap: too many rows");
+  if (dtype == PP_BF16 && HW % 16 == 0 && Cin % 32 == 0 && Cin <= 32 * FHM_MAXKS && K <= 144 &&
+      ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+    const int nt = cdiv(K, 16), tiles = (int)(M / 16);
+    const size_t lds_w = (size_t)nt * 16 * (Cin * 2 + 16);
+    const int grid = (int)std::min<long long>(cdiv(tiles, 4), 256 * 2);
+    hipStream_t sm = (hipStream_t)stream;
+#define PP_FHM(NT_)                                                                                       \
+  do {                                                                                                    \
+    if (lds_w > 64 * 1024)                                                                                \
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_mfma_kernel<NT_>),    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));          \
+    hipLaunchKernelGGL(final_heatmap_mfma_kernel<NT_>, dim3(grid), dim3(256), lds_w, sm, (const bf16_t *)x, \
+                       (const bf16_t *)w, bias, out, tiles, HW, Cin, K, temperature);                     \
+  } while (0)
+    if (nt <= 2) PP_FHM(2);
+    else if (nt <= 4) PP_FHM(4);
+    else PP_FHM(9);
+#undef PP_FHM
+    PP_CHECK_LAUNCH("final_heatmap_mfma_kernel");
+    return 0;
+  }
   const size_t lds = (size_t)FH_ROWS * (Cin / vec + 1) * 16 + (size_t)K * Cin * es;
   PP_REQUIRE(lds <= 160 * 1024, "pp_final_heatmap: K=%d x Cin=%d does not fit LDS", K, Cin);
   hipStream_t s = (hipStream_t)stream;

@@ -70,6 +70,8 @@ def all_gather_decoded(packed: torch.Tensor, group: Optional[dist.ProcessGroup] 
     if dist.get_backend(group) == "nccl":
         recv = torch.empty((world * Bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         dist.all_gather_into_tensor(recv, send, group=group)
+        if sizes is None:
+            return recv                      # even shards: the gathered buffer already is [world * B, K, 7]
         parts = list(recv.split(Bmax))
     else:
         parts = [torch.empty_like(send) for _ in range(world)]
