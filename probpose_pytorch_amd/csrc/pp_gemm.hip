@@ -19,6 +19,8 @@
 #include <type_traits>
 #include <utility>
 
+#include <algorithm>
+
 #include "pp_common.h"
 
 namespace pp {
@@ -84,6 +86,7 @@ struct GemmParams {
   float ln_eps;
   float out_scale;   // fp8 output: value * out_scale is what gets rounded to e4m3
   int blocked;       // XCD-blocked tile order (large grids) vs plain order
+  int rn;            // column tiles per XCD block (<= tiles_n, so narrow-N launches carry no empty slots)
   int lds_epilogue;  // bf16 C tile staged through LDS and stored as whole rows
 };
 
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
   // of an XCD's 32 CUs); block g goes to XCD g % 8 and blocks are numbered N-fastest, so an XCD
   // keeps working on the same few W column-slices (L2-resident) while A row-panels stream through,
   // each panel shared by the RN tiles of the block.  Out-of-range slots of partial blocks exit.
-  constexpr int RM = 8, RN = (NW == 8) ? 4 : 8, RT = RM * RN;
+  constexpr int RM = 8;
+  const int RN = p.rn, RT = RM * RN;
   int tm, tn;
   if (p.blocked) {
     const int nbm = (p.tiles_m + RM - 1) / RM, nbn = (p.tiles_n + RN - 1) / RN;
@@ -975,9 +979,15 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
-  const int rn_ = (cfg >= 3) ? 4 : 8;
-  const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
-  p.blocked = nblk >= 16 ? 1 : 0;
+  dim3 grid;
+  auto set_grid = [&](int c) {   // c = tile configuration; tiles_m / tiles_n are set
+    const int rn_ = std::min((c >= 3) ? 4 : 8, p.tiles_n);
+    const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
+    p.rn = rn_;
+    p.blocked = nblk >= 16 ? 1 : 0;
+    grid = dim3(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
+  };
+  set_grid(cfg);
   {
     const int oes = (a->dtype == PP_F32 || (a->epilogue & PP_EPI_OUT_F32)) ? 4 : ((a->epilogue & PP_EPI_OUT_FP8) ? 1 : 2),
               per16 = 16 / oes;
@@ -991,7 +1001,6 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   if (a->epilogue & PP_EPI_ROWSTATS)
     PP_REQUIRE(a->stats_parts == p.tiles_n, "pp_gemm: stats_parts=%d but this launch has %d column tiles",
                a->stats_parts, p.tiles_n);
-  dim3 grid(p.blocked ? (unsigned)(((nblk + 7) / 8) * 8 * 8 * rn_) : (unsigned)(p.tiles_m * p.tiles_n), batch);
   hipStream_t s = (hipStream_t)stream;
 #define PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_)                              \
   do {                                                                                                \
@@ -1020,9 +1029,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     cfg = 3;
     p.tiles_m = cdiv(a->M, 192);
     p.tiles_n = cdiv(a->N, 192);
-    const long long nb3 = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, 4);
-    p.blocked = nb3 >= 16 ? 1 : 0;
-    grid = dim3(p.blocked ? (unsigned)(((nb3 + 7) / 8) * 8 * 8 * 4) : (unsigned)(p.tiles_m * p.tiles_n), batch);
+    set_grid(3);
   }
   if (a->dtype == PP_FP8) {
     PP_REQUIRE(vec && p.lds_epilogue, "pp_gemm: fp8 needs the vector / LDS epilogue path (aligned N, ldc, C)");
@@ -1031,9 +1038,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
       cfg = 3;
       p.tiles_m = cdiv(a->M, 192);
       p.tiles_n = cdiv(a->N, 192);
-      const long long nb3 = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, 4);
-      p.blocked = nb3 >= 16 ? 1 : 0;
-      grid = dim3(p.blocked ? (unsigned)(((nb3 + 7) / 8) * 8 * 8 * 4) : (unsigned)(p.tiles_m * p.tiles_n), batch);
+      set_grid(3);
     }
     if (cfg == 2) PP_LAUNCH_GEMM_V(fp8_t, 192, 96, 2, 2, 2, false, true);
     else PP_LAUNCH_GEMM_V(fp8_t, 192, 192, 2, 4, 3, false, true);
