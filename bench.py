@@ -78,6 +78,25 @@ def pmc_traffic():
     return (b / n if n else None), dec, os.path.basename(files[-1])
 
 
+def measured_peaks():
+    """What tools/ubench/peaks measured on this device class (profiles/*_peaks.txt): bf16 MFMA TFLOP/s on random
+    operands (the chip lowers its clock under MFMA load) and HBM read / write GB/s.  Reported beside the spec
+    peaks, never instead of them."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_peaks.txt")))
+    if not files:
+        return None
+    txt = open(files[-1]).read()
+    mf = [float(v) for v in re.findall(r"random operands.*?(\d+) TFLOP/s", txt)]
+    rd = re.search(r"stream read\s+2048 MiB.*?(\d+) GB/s", txt)
+    wr = re.search(r"stream write\s+2048 MiB.*?(\d+) GB/s", txt)
+    if not mf or not rd or not wr:
+        return None
+    return {"mfma_bf16_random_tflops": round(sum(mf) / len(mf), 0), "hbm_read_gbps": float(rd.group(1)),
+            "hbm_write_gbps": float(wr.group(1)), "source": os.path.basename(files[-1])}
+
+
 def sigmas_for(K: int) -> np.ndarray:
     from probpose_pytorch_amd.synthetic import torch as _t  # noqa: F401
     if K == 17:
@@ -298,6 +317,11 @@ def main():
             "kernel_ms_per_step": {k: round(v[2] * 1e3, 3) for k, v in per_step.items()},
             "gemm_tiles_autotuned": tiles,
         }
+        mp = measured_peaks()
+        if mp is not None:
+            line["measured_device_peaks"] = mp
+            if args.dtype == "bf16":
+                line["roofline"]["frac_of_measured_mfma"] = round(achieved / mp["mfma_bf16_random_tflops"], 4)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(line))

@@ -202,6 +202,17 @@ int pp_frontend_crop_resize(const unsigned char *image, int img_w, int img_h, lo
                             const void *plan_dev, int n_boxes, int n_blocks, long long lds_bytes,
                             int out_w, int out_h, float *out, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Training targets: the OKS probability maps of ProbMap.encode, batched over crops.  Replaces
+ *   generate_probmaps   probpose/codec.py:11-70  (called from ProbMap.encode, codec.py:176-182)
+ * kpts_hm [B,K,2] f32: keypoints in HEATMAP pixels (= keypoints / scale_factor, codec.py:178);
+ * visible [B,K] f32; two_s [K] f64 = 2 * s_k with s_k the per-keypoint (or overriding) variance of
+ * codec.py:61-66, computed by the caller in float64.  Outputs: heatmaps [B,K,H,W] f32 (zero for
+ * visible < 0.5), weights [B,K] f32 (= visible for skipped keypoints, else map.max() > 0).
+ * ---------------------------------------------------------------------- */
+int pp_encode_probmaps(const float *kpts_hm, const float *visible, const double *two_s, int B, int K, int H,
+                       int W, float *heatmaps, float *weights, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

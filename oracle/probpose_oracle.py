@@ -325,3 +325,59 @@ def synthetic_heatmaps(B: int, K: int, H: int, W: int, seed: int, kind: str = "p
             out[b, k] = m
             n += 1
     return out
+
+
+# ---------------------------------------------------------------------------
+# Target generation: ProbMap.encode / generate_probmaps
+# ---------------------------------------------------------------------------
+def generate_probmaps(heatmap_size, keypoints, keypoints_visible, sigmas, sigma=0.55):
+    """Restatement of reference codec.py:11-70: per visible keypoint the OKS map
+    exp(-dist^2 / (2 s)) over the (H, W) grid, float64 arithmetic, stored float32; s = clip((2 sigma_k)^2 *
+    sqrt(H/1.25 * W/1.25) * 2, 0.55, 3.0) unless ``sigma`` > 0 overrides it; weight = (map max > 0)."""
+    N, K, _ = keypoints.shape
+    W, H = heatmap_size
+    heatmaps = np.zeros((K, H, W), dtype=np.float32)
+    weights = keypoints_visible.copy()
+    bbox_area = np.sqrt(H / 1.25 * W / 1.25)
+    yy, xx = np.indices((H, W))
+    for n in range(N):
+        for k in range(K):
+            if keypoints_visible[n, k] < 0.5:
+                continue
+            dx = xx - keypoints[n, k, 0]
+            dy = yy - keypoints[n, k, 1]
+            dist = np.sqrt(dx ** 2 + dy ** 2)
+            s = np.clip((sigmas[k] * 2) ** 2 * bbox_area * 2, 0.55, 3.0)
+            if sigma is not None and sigma > 0:
+                s = sigma
+            oks = np.exp(-(dist ** 2 / (2 * s)))
+            weights[n, k] = (oks.max() > 0).astype(int)
+            heatmaps[k] = oks
+    return heatmaps, weights
+
+
+def probmap_encode(keypoints, keypoints_visible, input_size, heatmap_size, sigmas, sigma=2.0):
+    """Restatement of reference codec.py:138-212 (the fields the training target uses)."""
+    scale_factor = ((np.array(input_size) - 1) / (np.array(heatmap_size) - 1)).astype(np.float32)
+    if keypoints_visible is None:
+        keypoints_visible = np.ones(keypoints.shape[:2], dtype=np.float32)
+    hm_kpts = keypoints / scale_factor
+    heatmaps, weights = generate_probmaps(heatmap_size, hm_kpts, keypoints_visible, sigmas, sigma)
+    in_image = ((keypoints[:, :, 0] >= 0) & (keypoints[:, :, 0] < input_size[0]) &
+                (keypoints[:, :, 1] >= 0) & (keypoints[:, :, 1] < input_size[1]))
+    return dict(heatmaps=heatmaps, keypoint_weights=weights, annotated=keypoints_visible > 0, in_image=in_image,
+                heatmap_keypoints=hm_kpts)
+
+
+def synthetic_keypoints(K: int, input_size, seed: int):
+    """Seeded (1, K, 2) float32 keypoints in input-image pixels (some outside the image) + (1, K) visibility
+    flags in {0, 1, 2}-style floats as dataset.py:116-118 produces them."""
+    rng = np.random.default_rng(seed)
+    w, h = input_size
+    kp = np.stack([rng.uniform(-0.15 * w, 1.15 * w, K), rng.uniform(-0.15 * h, 1.15 * h, K)], -1)[None].astype(np.float32)
+    vis = (rng.random((1, K)) > 0.2).astype(np.float32)
+    kp[0, 0] = (10.0, 20.0)          # exactly representable, well inside
+    kp[0, 1] = (-4000.0, -4000.0)    # so far away that exp underflows: weight 0
+    vis[0, 0] = vis[0, 1] = 1.0
+    return kp, vis
+

@@ -55,10 +55,57 @@ class ProbMap:
         out = self.decode_device(t)
         return out["kpts"].cpu().numpy(), out["scores"].cpu().numpy()
 
-    def encode(self, *args, **kwargs):
-        raise NotImplementedError(
-            "ProbMap.encode (training-target generation, reference codec.py:138-212) is outside "
-            "the forward+decode hot path built here")
+    def _two_s(self) -> np.ndarray:
+        """2 * s_k in float64, s_k as reference codec.py:61-66: clip((2 sigma_k)^2 * sqrt(H/1.25 * W/1.25) * 2,
+        0.55, 3.0), replaced by ``self.sigma`` when that is set and positive."""
+        W, H = self.heatmap_size
+        bbox_area = np.sqrt(H / 1.25 * W / 1.25)
+        s = np.clip((np.asarray(self.sigmas, dtype=np.float64) * 2) ** 2 * bbox_area * 2, 0.55, 3.0)
+        if self.sigma is not None and self.sigma > 0:
+            s = np.full_like(s, float(self.sigma))
+        return 2 * s
+
+    def encode_device(self, keypoints, keypoints_visible=None):
+        """Batched target generation on the GPU: keypoints (B, K, 2) in input-image pixels (numpy or tensor),
+        visibility (B, K) or None -> (heatmaps (B, K, H, W) f32, keypoint_weights (B, K) f32) device tensors.
+        Row b equals the reference ``encode(keypoints[b:b+1], ...)`` (codec.py:138-212, single instance)."""
+        _lib.require_device()
+        kp = np.asarray(keypoints.cpu() if isinstance(keypoints, torch.Tensor) else keypoints)
+        B, K = kp.shape[:2]
+        vis = (np.ones((B, K), dtype=np.float32) if keypoints_visible is None else
+               np.asarray(keypoints_visible.cpu() if isinstance(keypoints_visible, torch.Tensor) else keypoints_visible))
+        hm_kp = (kp[..., :2] / self.scale_factor).astype(np.float32)      # codec.py:178, float32 like the reference
+        W, H = self.heatmap_size
+        dev = torch.device("cuda", torch.cuda.current_device())
+        d_kp = torch.from_numpy(np.ascontiguousarray(hm_kp)).to(dev)
+        d_vis = torch.from_numpy(np.ascontiguousarray(vis, dtype=np.float32)).to(dev)
+        d_s = torch.from_numpy(self._two_s()).to(dev)
+        if d_s.numel() != K:
+            raise ValueError(f"{K} keypoints but {d_s.numel()} sigmas")
+        heat = torch.empty((B, K, H, W), dtype=torch.float32, device=dev)
+        wts = torch.empty((B, K), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().pp_encode_probmaps(_lib.ptr(d_kp), _lib.ptr(d_vis), _lib.ptr(d_s), B, K, H, W,
+                                               _lib.ptr(heat), _lib.ptr(wts), _lib.stream_ptr())
+        _lib.check(rc, "pp_encode_probmaps")
+        return heat, wts
+
+    def encode(self, keypoints, keypoints_visible=None, id_similarity=0.0, keypoints_visibility=None) -> dict:
+        """Reference codec.py:138-212: single-instance keypoints (1, K, D) in input-image pixels -> the target
+        dict (heatmaps (K, H, W) f32, keypoint_weights (1, K), annotated, in_image, keypoints_scaled,
+        heatmap_keypoints, identification_similarity); the maps are generated by the HIP kernel."""
+        assert keypoints.shape[0] == 1, f"{self.__class__.__name__} only support single-instance keypoint encoding"
+        if keypoints_visible is None:
+            keypoints_visible = np.ones(keypoints.shape[:2], dtype=np.float32)
+        heat, wts = self.encode_device(keypoints, keypoints_visible)
+        weights = keypoints_visible.copy()
+        weights[...] = wts.cpu().numpy().astype(weights.dtype)
+        in_image = np.logical_and(keypoints[:, :, 0] >= 0, keypoints[:, :, 0] < self.input_size[0])
+        in_image = np.logical_and(in_image, keypoints[:, :, 1] >= 0)
+        in_image = np.logical_and(in_image, keypoints[:, :, 1] < self.input_size[1])
+        return dict(heatmaps=heat[0].cpu().numpy(), keypoint_weights=weights, annotated=keypoints_visible > 0,
+                    in_image=in_image, keypoints_scaled=keypoints, heatmap_keypoints=keypoints / self.scale_factor,
+                    identification_similarity=id_similarity)
 
 
 class Codec:

@@ -117,6 +117,20 @@ def main():
                         vals=v_b, conv_sample=c_b[:, ::16, ::16].copy())
     print("bigmap", l_b.shape)
 
+    # G6: target generation, reference ProbMap.encode (codec.py:138-212) on seeded keypoints
+    for name, K, in_size, hm_size, sigmas, sigma, seed in (
+            ("encode_k17_sigma2", 17, (192, 256), (48, 64), coco, 2.0, 31),
+            ("encode_k17_persigma", 17, (192, 256), (48, 64), coco, None, 32),
+            ("encode_k133_sigma2", 133, (288, 384), (72, 96), k133_sigmas(), 2.0, 33)):
+        kp, vis = orc.synthetic_keypoints(K, in_size, seed)
+        enc = ProbMap(in_size, hm_size, sigmas, sigma=sigma).encode(kp.copy(), vis.copy())
+        hm = enc["heatmaps"]
+        keep = hm if K == 17 else hm[:12]
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kp_sha=sha(kp), heatmaps=keep, hm_sha=sha(hm),
+                            weights=enc["keypoint_weights"], annotated=enc["annotated"], in_image=enc["in_image"],
+                            heatmap_keypoints=enc["heatmap_keypoints"], sigma=np.array(-1.0 if sigma is None else sigma))
+        print(name, hm.shape, hm.dtype, "weights", enc["keypoint_weights"].ravel()[:4])
+
     # G3 / G4: head
     try:
         syn = _load("pp_synthetic_for_goldens", os.path.join(REPO, "probpose_pytorch_amd", "synthetic.py"))

@@ -186,3 +186,39 @@ def test_full_size_batch_properties(pp):
         # idempotence of the launch (no hidden state): second run is bit-identical
         again = probmap.decode_device(t)["kpts"].cpu().numpy()
         np.testing.assert_array_equal(again, kpts)
+
+
+# ---------------------------------------------------------------------------
+# Target generation: ProbMap.encode on the GPU vs goldens minted from the reference
+# ---------------------------------------------------------------------------
+ENCODE_CASES = [("encode_k17_sigma2", 17, (192, 256), (48, 64), "coco", 2.0, 31),
+                ("encode_k17_persigma", 17, (192, 256), (48, 64), "coco", None, 32),
+                ("encode_k133_sigma2", 133, (288, 384), (72, 96), "k133", 2.0, 33)]
+
+
+def _encode_sigmas(tag):
+    return orc.COCO17_SIGMAS if tag == "coco" else np.random.default_rng(133).uniform(0.02, 0.11, 133)
+
+
+@pytest.mark.parametrize("name,K,in_size,hm_size,sig,sigma,seed", ENCODE_CASES)
+def test_encode_matches_reference_golden(pp, name, K, in_size, hm_size, sig, sigma, seed):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    kp, vis = orc.synthetic_keypoints(K, in_size, seed)
+    enc = pp.ProbMap(in_size, hm_size, _encode_sigmas(sig), sigma=sigma).encode(kp.copy(), vis.copy())
+    n = g["heatmaps"].shape[0]
+    assert enc["heatmaps"].dtype == np.float32 and enc["heatmaps"].shape == (K, hm_size[1], hm_size[0])
+    assert np.array_equal(enc["heatmaps"][:n], g["heatmaps"])          # bit-exact float32 maps
+    assert np.array_equal(enc["keypoint_weights"], g["weights"])
+    assert np.array_equal(enc["in_image"], g["in_image"]) and np.array_equal(enc["annotated"], g["annotated"])
+    assert np.array_equal(enc["heatmap_keypoints"], g["heatmap_keypoints"])
+
+
+def test_encode_batched_equals_per_crop_oracle(pp):
+    pm = pp.ProbMap((192, 256), (48, 64), orc.COCO17_SIGMAS, sigma=None)
+    kps, viss = zip(*[orc.synthetic_keypoints(17, (192, 256), 100 + i) for i in range(5)])
+    heat, wts = pm.encode_device(np.concatenate(kps), np.concatenate(viss))
+    heat, wts = heat.cpu().numpy(), wts.cpu().numpy()
+    for i in range(5):
+        ref = orc.probmap_encode(kps[i], viss[i], (192, 256), (48, 64), orc.COCO17_SIGMAS, None)
+        assert np.array_equal(heat[i], ref["heatmaps"]) and np.array_equal(wts[i:i + 1], ref["keypoint_weights"])
+    assert pm.encode_device(np.zeros((0, 17, 2), np.float32))[0].shape == (0, 17, 64, 48)

@@ -140,3 +140,19 @@ def test_head_restatement_matches_reference_golden():
     np.testing.assert_array_equal(kpts, g["kpts"])
     np.testing.assert_array_equal(scores, g["scores"])
     np.testing.assert_array_equal(err, g["dec_err"])
+
+
+@pytest.mark.parametrize("name,K,in_size,hm_size,sig,sigma,seed", [
+    ("encode_k17_sigma2", 17, (192, 256), (48, 64), "coco", 2.0, 31),
+    ("encode_k17_persigma", 17, (192, 256), (48, 64), "coco", None, 32),
+    ("encode_k133_sigma2", 133, (288, 384), (72, 96), "k133", 2.0, 33)])
+def test_encode_restatement_equals_reference_golden(name, K, in_size, hm_size, sig, sigma, seed):
+    """G6: oracle.probmap_encode vs the imported reference's ProbMap.encode (codec.py:138-212)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sigmas = orc.COCO17_SIGMAS if sig == "coco" else np.random.default_rng(133).uniform(0.02, 0.11, 133)
+    kp, vis = orc.synthetic_keypoints(K, in_size, seed)
+    e = orc.probmap_encode(kp, vis, in_size, hm_size, sigmas, sigma)
+    n = g["heatmaps"].shape[0]
+    assert np.array_equal(e["heatmaps"][:n], g["heatmaps"])
+    assert np.array_equal(e["keypoint_weights"], g["weights"]) and np.array_equal(e["in_image"], g["in_image"])
+    assert np.array_equal(e["heatmap_keypoints"], g["heatmap_keypoints"])
