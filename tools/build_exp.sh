@@ -7,5 +7,5 @@ NAME=$1; shift
 mkdir -p "$ROOT/probpose_pytorch_amd/lib/exp"
 cd "$ROOT/probpose_pytorch_amd/csrc"
 hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-  "$@" pp_gemm.hip pp_capi.hip pp_ops.hip pp_attention.hip pp_decode.hip -o "../lib/exp/$NAME.so"
+  "$@" pp_*.hip -o "../lib/exp/$NAME.so"
 echo "built lib/exp/$NAME.so"

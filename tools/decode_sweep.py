@@ -7,6 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
+from probpose_pytorch_amd import _lib
+
+if "--lib" in sys.argv:      # A/B an experimental build of the library (tools/build_exp.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from probpose_pytorch_amd.heatmap import decode_on_device, oks_tap_table
 
 COCO = np.array([.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087, .087, .089, .089])
