@@ -151,6 +151,10 @@ int pp_layernorm_fp8(const float *x, const float *gamma, const float *beta, floa
  * reshape(B,N,3,heads,hd)); out [B*N, heads*hd]. */
 int pp_attention(const void *qkv, void *out, int B, int N, int heads, int hd,
                  int dtype, void *stream);
+/* Same on bf16 qkv, output quantised to OCP e4m3: out[., c] = e4m3(o * inv_scale) (fp8 mode: the A operand of
+ * the fp8 proj GEMM).  MFMA kernels only (head_dim 32 / 64 / 80). */
+int pp_attention_fp8out(const void *qkv, unsigned char *out, int B, int N, int heads, int hd,
+                        float inv_scale, void *stream);
 
 /* Patch im2col + cast: x [B,3,H,W] f32 NCHW -> A [B*gh*gw, 3*p*p] (k = c*p*p + py*p + px),
  * the A operand of patch_embed.proj as a GEMM (timm PatchEmbed, stride = patch). */

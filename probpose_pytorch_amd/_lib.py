@@ -51,6 +51,7 @@ _SIGNATURES = {
     "pp_layernorm": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "pp_layernorm_fp8": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _f, _vp]),
     "pp_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pp_attention_fp8out": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pp_final_heatmap": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -77,6 +77,17 @@ __device__ __forceinline__ void att_glds16(const void *gsrc, unsigned lds_off_un
       : "memory");
 }
 
+// OCP e4m3, saturating at +-448 (fp8 mode: the attention output feeds the fp8 proj GEMM)
+__device__ __forceinline__ unsigned att_pack_fp8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
+  b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+  c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f);
+  d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
 }
@@ -84,7 +95,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 template <int AT_HD>
 __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__restrict__ qkv,
                                                                 bf16_t *__restrict__ out, int N,
-                                                                int heads, float scale_log2e) {
+                                                                int heads, float scale_log2e, float fp8_inv_scale) {
   using G = AttGeom<AT_HD>;
   constexpr int AT_KROW = G::KROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,6 +266,15 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
   for (int t = 0; t < AT_QT; ++t) {
     const int q = q0 + t * 16 + lrow;
     if (q >= N) continue;
+    if (fp8_inv_scale > 0.f) {   // out is an e4m3 byte tensor [B*N, C]
+      unsigned char *orow8 = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * C + h * AT_HD;
+      const float sc = inv_l[t] * fp8_inv_scale;
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+        *reinterpret_cast<unsigned *>(orow8 + dt * 16 + g * 4) =
+            att_pack_fp8x4(oacc[dt][t][0] * sc, oacc[dt][t][1] * sc, oacc[dt][t][2] * sc, oacc[dt][t][3] * sc);
+      continue;
+    }
     bf16_t *orow = out + ((size_t)b * N + q) * C + h * AT_HD;
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) {
@@ -284,7 +304,7 @@ constexpr int ST_KB = 96;
 template <int HD>
 __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *__restrict__ qkv,
                                                                   bf16_t *__restrict__ out, int N, int heads,
-                                                                  int qblocks, float scale_log2e) {
+                                                                  int qblocks, float scale_log2e, float fp8_inv_scale) {
   using G = AttGeom<HD>;
   constexpr int KROW = G::KROW;
   constexpr int BLK_BYTES = ST_KB * KROW;
@@ -441,6 +461,15 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
     const float inv_l = 1.0f / l;
     const int q = q0 + t * 16 + lrow;
     if (q >= N) continue;
+    if (fp8_inv_scale > 0.f) {
+      unsigned char *orow8 = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * C + h * HD;
+      const float sc = inv_l * fp8_inv_scale;
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+        *reinterpret_cast<unsigned *>(orow8 + dt * 16 + g * 4) =
+            att_pack_fp8x4(oacc[dt][t][0] * sc, oacc[dt][t][1] * sc, oacc[dt][t][2] * sc, oacc[dt][t][3] * sc);
+      continue;
+    }
     bf16_t *orow = out + ((size_t)b * N + q) * C + h * HD;
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) {
@@ -453,18 +482,18 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
 }
 
 template <int HD>
-static void launch_stream(const void *qkv, void *out, int B, int N, int heads, hipStream_t s) {
+static void launch_stream(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s) {
   const int qblocks = (N + 4 * ST_QT * 16 - 1) / (4 * ST_QT * 16);
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
   hipLaunchKernelGGL(attention_stream_kernel<HD>, dim3((unsigned)((size_t)B * heads * qblocks)), dim3(256),
                      2 * ST_KB * AttGeom<HD>::KROW, s, (const bf16_t *)qkv, (bf16_t *)out, N, heads, qblocks,
-                     scale_log2e);
+                     scale_log2e, fp8_inv_scale);
 }
 
 }  // namespace pp
 
-extern "C" int pp_attention(const void *qkv, void *out, int B, int N, int heads, int hd, int dtype,
-                            void *stream) {
+static int attention_dispatch(const void *qkv, void *out, int B, int N, int heads, int hd, int dtype,
+                              float fp8_inv_scale, void *stream) {
   using namespace pp;
   PP_REQUIRE(B >= 0 && N > 0 && heads > 0 && hd > 0, "pp_attention: bad shape");
   if (B == 0) return 0;
@@ -475,23 +504,36 @@ extern "C" int pp_attention(const void *qkv, void *out, int B, int N, int heads,
       const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
       if (hd == 64)
         hipLaunchKernelGGL(attention_mfma_kernel<64>, dim3(B * heads), dim3(256), AttGeom<64>::LDS, s,
-                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e);
+                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e, fp8_inv_scale);
       else
         hipLaunchKernelGGL(attention_mfma_kernel<32>, dim3(B * heads), dim3(256), AttGeom<32>::LDS, s,
-                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e);
+                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e, fp8_inv_scale);
       PP_CHECK_LAUNCH("attention_mfma_kernel");
       return 0;
     }
     if ((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 &&
         (size_t)B * heads * ((N + 127) / 128) < (1ull << 31)) {
-      if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, s);
-      else if (hd == 64) launch_stream<64>(qkv, out, B, N, heads, s);
-      else launch_stream<32>(qkv, out, B, N, heads, s);
+      if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, fp8_inv_scale, s);
+      else if (hd == 64) launch_stream<64>(qkv, out, B, N, heads, fp8_inv_scale, s);
+      else launch_stream<32>(qkv, out, B, N, heads, fp8_inv_scale, s);
       PP_CHECK_LAUNCH("attention_stream_kernel");
       return 0;
     }
+    PP_REQUIRE(fp8_inv_scale <= 0.f, "pp_attention_fp8out: needs head_dim 32 / 64 / 80 and aligned operands");
     return attention_valu<bf16_t>(qkv, out, B, N, heads, hd, s);
   }
+  PP_REQUIRE(fp8_inv_scale <= 0.f, "pp_attention_fp8out: bf16 qkv only");
   if (dtype == PP_F32) return attention_valu<float>(qkv, out, B, N, heads, hd, s);
   return fail("pp_attention: bad dtype %d", dtype);
+}
+
+extern "C" int pp_attention(const void *qkv, void *out, int B, int N, int heads, int hd, int dtype,
+                            void *stream) {
+  return attention_dispatch(qkv, out, B, N, heads, hd, dtype, 0.f, stream);
+}
+
+extern "C" int pp_attention_fp8out(const void *qkv, unsigned char *out, int B, int N, int heads, int hd,
+                                   float inv_scale, void *stream) {
+  if (!(inv_scale > 0.f)) return pp::fail("pp_attention_fp8out: inv_scale must be positive");
+  return attention_dispatch(qkv, out, B, N, heads, hd, PP_BF16, inv_scale, stream);
 }

@@ -204,7 +204,13 @@ def layernorm(x, gamma, beta, eps, out, out_scale=None):
     return out
 
 
-def attention(qkv, out, B, N, heads, hd):
+def attention(qkv, out, B, N, heads, hd, out_scale=None):
+    if out.dtype == FP8:     # e4m3 output with a static per-tensor scale (fp8 mode)
+        rc = _timed("attention", 4.0 * B * heads * N * N * hd,
+                    lambda: _lib.lib().pp_attention_fp8out(_p(qkv), _p(out), B, N, heads, hd, 1.0 / float(out_scale),
+                                                           _lib.stream_ptr()))
+        _lib.check(rc, "pp_attention_fp8out")
+        return out
     rc = _timed("attention", 4.0 * B * heads * N * N * hd,
                 lambda: _lib.lib().pp_attention(_p(qkv), _p(out), B, N, heads, hd, dtype_code(qkv.dtype),
                                                 _lib.stream_ptr()))

@@ -222,10 +222,13 @@ def test_run_inference_on_boxes_matches_crop_then_forward(pkg):
     np.testing.assert_allclose(frame_kpts[1], preds[0][0][1] / [192, 256] * [150.0, 300.0] + [300.5, 100.25])
 
 
-def test_fp8_forward_tracks_bf16(pkg):
+@pytest.mark.parametrize("fp8_proj", [False, True])
+def test_fp8_forward_tracks_bf16(pkg, fp8_proj, monkeypatch):
     """BASELINE config 5 (fp8 weights / activations on the fp8 MFMA): same model, bf16 vs fp8 ViT GEMMs.
     No reference exists for fp8 (the reference is fp32-only): the deviation from the bf16 path is bounded loosely and
     the decode of the fp8 heatmaps must stay well-formed; determinism and graph capture after calibration are checked."""
+    from probpose_pytorch_amd import engine
+    monkeypatch.setattr(engine, "FP8_PROJ", fp8_proj)
     model, _ = _build(pkg, (256, 192), 384, 4, 12, 17, [(4, 3), (2, 2), (2, 2)])
     x = pkg["syn"].synthetic_crops(8, 256, 192, seed=3).cuda()
     with torch.no_grad():
@@ -238,7 +241,7 @@ def test_fp8_forward_tracks_bf16(pkg):
         assert torch.equal(a, b)
     d = (out[0] - ref[0]).abs()
     assert out[0].shape == ref[0].shape and torch.isfinite(out[0]).all()
-    assert float(d.mean()) < 0.03 and float(d.max()) < 0.5, (float(d.mean()), float(d.max()))
+    assert float(d.mean()) < 0.03 and float(d.max()) < 0.75, (float(d.mean()), float(d.max()))
     for a, b in zip(out[1:], ref[1:]):
         assert float((a - b).abs().max()) < 0.25
     g = torch.cuda.CUDAGraph()

@@ -374,3 +374,20 @@ def test_layernorm_fp8(ops):
     # saturation instead of NaN: values beyond the scale clamp to +-448
     ops.layernorm(x, gam, bet, 1e-6, out, out_scale=scale / 4)
     assert torch.isfinite(out.float()).all() and float(out.float().abs().max()) == 448.0
+
+
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 192, 4, 64), (1, 432, 2, 80), (1, 192, 3, 32), (1, 70, 2, 64)])
+def test_attention_fp8_output(ops, B, N, heads, hd):
+    """fp8 mode: same attention, output stored as e4m3(o / scale) == the bf16-path result quantised the same way
+    (up to one e4m3 step where the bf16 rounding of the reference path moved a value across a boundary)."""
+    C = heads * hd
+    qkv = _rand((B * N, 3 * C), torch.bfloat16, 1)
+    ref = torch.empty((B * N, C), dtype=torch.bfloat16, device="cuda")
+    ops.attention(qkv, ref, B, N, heads, hd)
+    scale = float(ref.float().abs().max()) / 448.0
+    out8 = torch.empty((B * N, C), dtype=torch.float8_e4m3fn, device="cuda")
+    ops.attention(qkv, out8, B, N, heads, hd, out_scale=scale)
+    got = out8.float() * scale
+    err = (got - ref.float()).abs()
+    assert bool((err <= ref.float().abs() * 2 ** -3 + scale * 2 ** -8).all())
+    assert float(err.mean()) < float(ref.float().abs().mean()) * 0.05
