@@ -6,16 +6,18 @@
 // A rows optionally addressed through a gather table (implicit GEMM, no im2col
 // buffer), C rows optionally scattered through a row map.
 //
-// Structure (CDNA4): BM x BN output tile per 256-thread workgroup (4 waves as
-// 2x2, each (BM/2)x(BN/2) = TMxTN MFMA 16x16 tiles), two instantiations:
-// 192x96 (one crop's 192 tokens per M-tile: at B = 64 the four ViT GEMMs are
-// exactly 1/3/4/1 rounds of 512 resident workgroups, no tail) and 128x128;
-// K-tiles of 128 B per row
-// (64 bf16 / 32 fp32) staged HBM->LDS by global_load_lds_dwordx4 (no VGPR
-// round trip) into a double buffer, XOR-swizzled on the SOURCE address so the
-// LDS image stays lane-linear for the DMA while ds_read_b128 fragment reads
-// are bank-conflict free.  bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode):
-// v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain.
+// Structure (CDNA4): BM x BN output tile per workgroup of WGM x WGN waves, each wave TM x TN MFMA 16x16
+// tiles.  Instantiations (pp_gemm's `tile` selector): 128x128, 192x96 (4 waves, 2 LDS stages, two workgroups
+// per CU), 192x192 / 192x128 (8 waves, 3 stages, one workgroup per CU), 384x128, 192x384, 256x256, 192x256
+// (8 waves, 2 stages).  192 rows = one crop's tokens, so at B = 64 the four ViT GEMMs are whole rounds.
+// K-tiles of 128 B per row (64 bf16 / 32 fp32 / 128 fp8) are staged HBM/L2 -> LDS by global_load_lds_dwordx4
+// (no VGPR round trip) into a 2- or 3-deep ring: counted s_waitcnt vmcnt(N) + one raw s_barrier per K-tile,
+// the DMA pieces issued between the MFMA groups; the 16-B chunks are XOR-swizzled on the SOURCE address
+// so the LDS image stays lane-linear for the DMA while ds_read_b128 fragment reads are bank-conflict free.
+// bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain;
+// fp8 (e4m3): v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, dequantised per column in the epilogue.
+// Epilogues: bias / row bias / GELU / ReLU / in-place fp32 residual / NCHW heatmap store, the C tile staged
+// through the dead K-loop buffers and stored as whole rows; optional LayerNorm producer / consumer modes.
 #include <type_traits>
 #include <utility>
 
