@@ -1,8 +1,8 @@
 // Multi-head self-attention (timm Attention.forward semantics:
 // softmax(q k^T * hd^-1/2) v per (crop, head)).  N = 192 tokens at 256x192, so
-// one (crop, head) problem lives entirely on a CU: no online-softmax tiling.
+// one (crop, head) problem (K and V: 48 KB) lives entirely on a CU.
 //
-// bf16 MFMA kernel (head_dim 64, N <= 192), one workgroup = 4 waves per
+// One-shot bf16 MFMA kernel (head_dim 64 / 32, N <= 192), one workgroup = 4 waves per
 // (crop, head), 48 query rows per wave:
 //   S^T = K Q^T      keys on the MFMA row axis, queries on the lane (column)
 //                    axis, so a query's scores sit in one lane quartet and the
