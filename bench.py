@@ -181,9 +181,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # PP_BENCH_REHEARSAL=1: every rank on GPU 0 and gloo instead of RCCL, to walk the multi-rank code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); never a measurement
+    rehearsal = os.environ.get("PP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 and rehearsal:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -261,7 +268,7 @@ def main():
         sync_all()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert result.shape == (B * world, cfg["K"], 7)

@@ -74,8 +74,12 @@ def all_gather_decoded(packed: torch.Tensor, group: Optional[dist.ProcessGroup] 
             return recv                      # even shards: the gathered buffer already is [world * B, K, 7]
         parts = list(recv.split(Bmax))
     else:
-        parts = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(parts, send, group=group)
+        # gloo (CPU tests, single-GPU rehearsals of the multi-rank path): the collective runs on host copies
+        host = send.cpu() if send.is_cuda else send
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        if send.is_cuda:
+            parts = [p.to(send.device) for p in parts]
     if sizes is not None:
         parts = [p[:n] for p, n in zip(parts, sizes)]
     return torch.cat(parts, 0)
