@@ -255,3 +255,22 @@ def test_fp8_forward_tracks_bf16(pkg, fp8_proj, monkeypatch):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(cap[0].float(), out[0])
+
+
+def test_optional_schedules_give_identical_results(pkg, monkeypatch):
+    """engine.DUAL_CHAIN (two half-batch kernel chains on two streams) and engine.SERIALIZE_HEAD (no aux stream)
+    only change the schedule: outputs must be bit-identical to the default path."""
+    from probpose_pytorch_amd import engine
+    model, _ = _build(pkg, (256, 192), 384, 3, 12, 17, [(4, 3), (2, 2), (2, 2)])
+    model.set_compute_dtype(torch.bfloat16)
+    x = pkg["syn"].synthetic_crops(16, 256, 192, seed=5).cuda()
+    with torch.no_grad():
+        ref = [t.clone() for t in model(x)]
+        monkeypatch.setattr(engine, "DUAL_CHAIN", True)
+        dual = [t.clone() for t in model(x)]
+        monkeypatch.setattr(engine, "DUAL_CHAIN", False)
+        monkeypatch.setattr(engine, "SERIALIZE_HEAD", True)
+        serial = [t.clone() for t in model(x)]
+    torch.cuda.synchronize()
+    for a, b, c in zip(ref, dual, serial):
+        assert torch.equal(a, b) and torch.equal(a, c)
