@@ -29,6 +29,9 @@ namespace pp {
 constexpr int FE_PRECISION_BITS = 32 - 8 - 2;   // Pillow Resample.c PRECISION_BITS
 constexpr int FE_HDR = 16;                      // int32 words per box header
 constexpr int FE_THREADS = 256;
+#ifndef FE_UNROLL
+#define FE_UNROLL 4     // taps in flight per thread in the horizontal pass (measured: 1 -> 4: 188 -> 170 us per 64 crops; 8: same)
+#endif
 constexpr size_t FE_LDS_TARGET = 64 * 1024, FE_LDS_MAX = 152 * 1024;
 
 // header words
@@ -167,19 +170,30 @@ __global__ __launch_bounds__(FE_THREADS) void crop_resize_kernel(const unsigned 
         // one (unaligned) dword load per pixel instead of three byte loads; the 4th byte is ignored.  The
         // frame's very last pixel is read bytewise so that nothing past the buffer is touched.
         const bool last_row = iy == img_h - 1;
-        for (int x = 0; x < xmax; ++x) {
-          const int ix = x0 + xmin + x;
-          if (ix >= 0 && ix < img_w) {
-            const int kx = k[x];
-            const unsigned char *px = row + 3 * ix;
-            unsigned rgb;
-            if (last_row && ix == img_w - 1)
-              rgb = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
-            else
-              __builtin_memcpy(&rgb, px, 4);
-            a0 += (int)(rgb & 255u) * kx;
-            a1 += (int)((rgb >> 8) & 255u) * kx;
-            a2 += (int)((rgb >> 16) & 255u) * kx;
+        // four taps per trip: the four pixel loads (and coefficient loads) are independent, so they are in flight
+        // together; taps past xmax or outside the frame contribute 0 (a zero pixel, as Image.crop pads)
+        for (int x = 0; x < xmax; x += FE_UNROLL) {
+          unsigned rgb[FE_UNROLL];
+          int kx[FE_UNROLL];
+#pragma unroll
+          for (int u = 0; u < FE_UNROLL; ++u) {
+            const int ix = x0 + xmin + x + u;
+            rgb[u] = 0;
+            kx[u] = 0;
+            if (x + u < xmax && ix >= 0 && ix < img_w) {
+              kx[u] = k[x + u];
+              const unsigned char *px = row + 3 * ix;
+              if (last_row && ix == img_w - 1)
+                rgb[u] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+              else
+                __builtin_memcpy(&rgb[u], px, 4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < FE_UNROLL; ++u) {
+            a0 += (int)(rgb[u] & 255u) * kx[u];
+            a1 += (int)((rgb[u] >> 8) & 255u) * kx[u];
+            a2 += (int)((rgb[u] >> 16) & 255u) * kx[u];
           }
         }
         v0 = fe_clip8(a0);

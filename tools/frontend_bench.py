@@ -11,7 +11,10 @@ import torch
 import __graft_entry__ as g
 
 g.build()
-from probpose_pytorch_amd import frontend
+from probpose_pytorch_amd import _lib, frontend
+
+if "--lib" in sys.argv:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 
 rng = np.random.default_rng(0)
 H, W, n = 1080, 1920, 64
