@@ -35,8 +35,9 @@ constexpr int FE_THREADS = 256;
 constexpr size_t FE_LDS_TARGET = 64 * 1024, FE_LDS_MAX = 152 * 1024;
 
 // header words
-enum { H_X0 = 0, H_Y0, H_CW, H_CH, H_KSH, H_KSV, H_YFIRST, H_YROWS, H_OFF_BH, H_OFF_KH, H_OFF_BV, H_OFF_KV,
-       H_NEED_H, H_NEED_V, H_RB, H_BLOCK0 };
+enum { H_X0 = 0, H_Y0, H_CW, H_CH, H_KSH, H_KSV, H_COEF_OFF, H_SRC_OFF, H_OFF_BH, H_OFF_KH, H_OFF_BV, H_OFF_KV,
+       H_NEED_H, H_NEED_V, H_RB, H_STAGED };
+constexpr int FE_SRC_ROWS = 8;              // source rows staged in LDS per trip of the horizontal pass
 
 static inline double fe_sinc(double x) {
   if (x == 0.0) return 1.0;
@@ -92,7 +93,9 @@ static int fe_coeffs(int inSize, int outSize, std::vector<int> &bounds, std::vec
 struct FeBox {
   std::vector<int> bh, kh, bv, kv;
   int ksh, ksv, rb, nblocks;
-  size_t lds;
+  size_t lds;                    // total LDS of a workgroup of this box
+  size_t coef_off, src_off;      // staged horizontal pass: byte offsets of the coefficient table / source-row buffer
+  bool staged;
 };
 
 // Output rows per workgroup: as many as keep >= 1024 workgroups in the launch (4 per CU; fewer, longer
@@ -119,10 +122,17 @@ static int fe_prepare(const int *box, int out_w, int out_h, int rb_max, FeBox &b
   for (int rb = rb_max; rb >= 1; rb >>= 1) {
     int span = 0;
     for (int r0 = 0; r0 < out_h; r0 += rb) span = std::max(span, fe_span(b.bv, out_h, r0, rb));
-    const size_t lds = (size_t)span * out_w * 3;
+    const size_t lds = ((size_t)span * out_w * 3 + 15) & ~(size_t)15;
     if (lds <= FE_LDS_TARGET || (rb == 1 && lds <= FE_LDS_MAX)) {
       b.rb = rb;
       b.lds = lds;
+      // staged horizontal pass when its tables fit beside the temporary rows
+      const size_t coef = (((size_t)out_w * (b.ksh + 2) * sizeof(int)) + 15) & ~(size_t)15;
+      const size_t src = (size_t)FE_SRC_ROWS * ((((size_t)3 * cw + 3) & ~(size_t)3) + 4);
+      b.staged = lds + coef + src <= 2 * FE_LDS_TARGET && lds + coef + src <= FE_LDS_MAX;
+      b.coef_off = lds;
+      b.src_off = lds + coef;
+      if (b.staged) b.lds = lds + coef + ((src + 15) & ~(size_t)15);
       break;
     }
   }
@@ -156,7 +166,74 @@ __global__ __launch_bounds__(FE_THREADS) void crop_resize_kernel(const unsigned 
   const int s0 = bv[r0 * 2], s1 = bv[(r1 - 1) * 2] + bv[(r1 - 1) * 2 + 1];
   const int span = s1 - s0;
 
-  // ---- horizontal pass (or copy) of crop rows [s0, s1) into LDS; pixels outside the image are 0 (Image.crop)
+  if (h[H_STAGED]) {
+    // ---- staged horizontal pass: the block's source rows go through LDS FE_SRC_ROWS at a time with coalesced dword
+    // loads (a wave reads 256 contiguous bytes; unaligned dword addresses are fine on gfx9), the box's bounds +
+    // coefficient rows sit in LDS too ([out_w][2 + ksh] ints, odd stride: conflict-free), so a tap costs three LDS
+    // byte reads + one LDS coefficient read instead of a scattered global dword load + a scattered coefficient load.
+    const int cw = h[H_CW];
+    int *coef = reinterpret_cast<int *>(tmp + h[H_COEF_OFF]);
+    unsigned char *src = tmp + h[H_SRC_OFF];
+    const int cstride = ksh + 2;
+    const int srcrow = ((3 * cw + 3) & ~3) + 4, ndw = (3 * cw + 3) >> 2;
+    if (need_h)
+      for (int i = threadIdx.x; i < out_w * cstride; i += FE_THREADS) {
+        const int xx = i / cstride, j = i - xx * cstride;
+        coef[i] = j < 2 ? bh[xx * 2 + j] : kh[(size_t)xx * ksh + (j - 2)];
+      }
+    const int rowbytes = 3 * img_w;
+    for (int c0 = 0; c0 < span; c0 += FE_SRC_ROWS) {
+      const int nrows = min(FE_SRC_ROWS, span - c0);
+      for (int i = threadIdx.x; i < nrows * ndw; i += FE_THREADS) {
+        const int rr = i / ndw, d = i - rr * ndw;
+        const int iy = y0 + s0 + c0 + rr;
+        const int o = 3 * x0 + 4 * d;                  // byte offset inside the frame row (may lie outside it)
+        unsigned v = 0;
+        if (iy >= 0 && iy < img_h) {
+          const unsigned char *row = image + (long long)iy * img_stride;
+          if (o >= 0 && o + 4 <= rowbytes) {
+            __builtin_memcpy(&v, row + o, 4);
+          } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              if (o + b >= 0 && o + b < rowbytes) v |= (unsigned)row[o + b] << (8 * b);
+          }
+        }
+        *reinterpret_cast<unsigned *>(src + rr * srcrow + 4 * d) = v;
+      }
+      __syncthreads();
+      for (int it = threadIdx.x; it < nrows * out_w; it += FE_THREADS) {
+        const int rr = it / out_w, xx = it - rr * out_w;
+        const unsigned char *srow = src + rr * srcrow;
+        int v0, v1, v2;
+        if (need_h) {
+          const int *cx = coef + xx * cstride;
+          const int xmin = cx[0], xmax = cx[1];
+          const unsigned char *px = srow + 3 * xmin;
+          int a0 = 1 << (FE_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+          for (int x = 0; x < xmax; ++x) {   // (a 4-tap unrolled form of this LDS loop measured 2x slower)
+            const int kx = cx[2 + x];
+            a0 += (int)px[3 * x] * kx;
+            a1 += (int)px[3 * x + 1] * kx;
+            a2 += (int)px[3 * x + 2] * kx;
+          }
+          v0 = fe_clip8(a0);
+          v1 = fe_clip8(a1);
+          v2 = fe_clip8(a2);
+        } else {
+          v0 = srow[3 * xx];
+          v1 = srow[3 * xx + 1];
+          v2 = srow[3 * xx + 2];
+        }
+        unsigned char *t = tmp + ((size_t)(c0 + rr) * out_w + xx) * 3;
+        t[0] = (unsigned char)v0;
+        t[1] = (unsigned char)v1;
+        t[2] = (unsigned char)v2;
+      }
+      __syncthreads();
+    }
+  } else
+  // ---- direct horizontal pass (or copy) of crop rows [s0, s1) into LDS; pixels outside the image are 0 (Image.crop)
   for (int it = threadIdx.x; it < span * out_w; it += FE_THREADS) {
     const int tr = it / out_w, xx = it - tr * out_w;
     const int iy = y0 + s0 + tr;
@@ -325,12 +402,12 @@ extern "C" int pp_frontend_plan_build(int n_boxes, const int *boxes_xyxy, int ou
     h[H_CH] = ch;
     h[H_KSH] = b.ksh;
     h[H_KSV] = b.ksv;
-    h[H_YFIRST] = b.bv[0];
-    h[H_YROWS] = b.bv[(size_t)out_h * 2 - 2] + b.bv[(size_t)out_h * 2 - 1] - b.bv[0];
+    h[H_COEF_OFF] = (int)b.coef_off;
+    h[H_SRC_OFF] = (int)b.src_off;
     h[H_NEED_H] = cw != out_w;   // Resample.c: need_horizontal = xsize != imIn->xsize || box[0] || box[2] != xsize
     h[H_NEED_V] = ch != out_h;
     h[H_RB] = b.rb;
-    h[H_BLOCK0] = 0;
+    h[H_STAGED] = b.staged ? 1 : 0;
     auto put = [&](int slot, const std::vector<int> &v) {
       h[slot] = (int)off;
       memcpy(w + off, v.data(), v.size() * sizeof(int));
