@@ -11,13 +11,15 @@
  * Conventions
  *   - plain C: pointers + sizes, no torch types.  All device buffers are
  *     caller-owned (torch tensors' data_ptr()); nothing is allocated here
- *     except inside pp_engine_create (weights arena, freed by pp_engine_destroy).
+ *     (where an entry point needs scratch, a *_workspace_bytes query sizes it).
  *   - every launch takes an explicit hipStream_t (as void*); calls are
  *     asynchronous and capturable into a hipGraph (no sync, no malloc).
  *   - return value: 0 = ok, <0 = error; pp_last_error() gives the message
  *     (thread-local).  No exceptions cross the ABI.
  *   - dtype enum: PP_F32 = 0 (fp32 storage, exact-fp32 MFMA), PP_BF16 = 1
- *     (bf16 storage, bf16 MFMA, fp32 accumulate).
+ *     (bf16 storage, bf16 MFMA, fp32 accumulate), PP_FP8 = 2 (OCP e4m3 storage,
+ *     block-scaled fp8 MFMA, fp32 accumulate; pp_gemm / pp_layernorm_fp8 /
+ *     pp_attention_fp8out only).
  */
 #ifndef PROBPOSE_HIP_H
 #define PROBPOSE_HIP_H
@@ -51,6 +53,7 @@ extern "C" {
                                            applies out = rstd_m * (acc - mean_m * colsum[n]) + bias[n] with mean/rstd
                                            from stats_in (exactly LN(x) W^T + b in exact arithmetic)                */
 #define PP_EPI_OUT_FP8 512              /* fp8 GEMM only: store e4m3(value * out_scale) instead of bf16 (the next fp8 GEMM's A) */
+#define PP_EPI_NOCLAMP 1024             /* with PP_EPI_HEATMAP: store v / temperature unclamped (the Sparsemax path, head.py:526-528) */
 #define PP_EPI_HEATMAP 64               /* head.py:526-532: f32 NCHW store of clamp(v / temperature, 0, 1):
                                            C[((r / hm_HW) * hm_K + n) * hm_HW + r % hm_HW], r = output row */
 
@@ -172,6 +175,16 @@ int pp_maxpool_relu(const void *x, void *out, int B, int h, int w, int C, int kh
  * LDS; larger final layers / k > 1 kernels go through pp_gemm with PP_EPI_HEATMAP.) */
 int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B, int HW,
                      int Cin, int K, float temperature, int dtype, void *stream);
+
+/* Same contraction without the clamp: logits = (x w^T + bias) / temperature, the input of the Sparsemax
+ * normalisation (head.py:526-528 with normalize != None). */
+int pp_final_logits(const void *x, const void *w, const float *bias, float *out, int B, int HW,
+                    int Cin, int K, float temperature, int dtype, void *stream);
+
+/* Sparsemax over the last axis of x [rows, n] f32 (in place), then * scale and clamp(0, 1): head.py:237-245
+ * (normalize_layer = Sparsemax(dim=-1), third-party sparsemax==0.1.9: restated from the published algorithm,
+ * Martins & Astudillo 2016 -- parity unpinned) + head.py:529-531 (x * normalize, clamp).  One workgroup per row. */
+int pp_sparsemax_rows(float *x, long long rows, int n, float scale, void *stream);
 
 /* Aux tail: 1x1 conv C->K on pooled 1x1 features + Sigmoid/ReLU (head.py:277-286,:391-400).
  * x [4 branches][B, C] -> out [4][B,K] f32 (branches 0..2 sigmoid, 3 relu). */

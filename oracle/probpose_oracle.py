@@ -13,6 +13,9 @@ Parity pinning (see DESIGN.md "Oracle"):
     ``tests/golden/decode_*.npz`` minted by ``tests/golden/make_goldens.py``.
   * head    (rows H1-H6): pinned against the imported reference
     ``probpose.head.ProbMapHead`` through ``tests/golden/head_*.npz``.
+  * Sparsemax (row H4, normalize != None): sparsemax==0.1.9 is not installed and
+    not vendored -> PARITY UNPINNED; ``sparsemax_lastdim`` restates the published
+    algorithm and is property-checked (simplex, support rule, KKT) in the tests.
   * backbone (rows B1-B6): the arithmetic lives in timm==1.0.15, which is not
     installed and not vendored -> PARITY UNPINNED by the reference; the
     restatement follows timm's published VisionTransformer semantics and is
@@ -252,6 +255,22 @@ def _bn(sd, p, x):
                         sd[p + "weight"], sd[p + "bias"], False, 0.0, 1e-5)
 
 
+def sparsemax_lastdim(x: torch.Tensor) -> torch.Tensor:
+    """Sparsemax(dim=-1) (head.py:241, third-party ``sparsemax==0.1.9``: NOT in the reference checkout, not
+    importable here -> PARITY UNPINNED).  Restated from the published algorithm (Martins & Astudillo 2016,
+    "From Softmax to Sparsemax", Algorithm 1) in the order the library's forward evaluates it, in the input's
+    dtype: shift by the row maximum, sort descending, cumulative sums, support size
+    k = max{ j : 1 + j z_(j) > sum_{i<=j} z_(i) }, tau = (sum_{i<=k} z_(i) - 1) / k, output max(z - tau, 0)."""
+    z = x - x.max(dim=-1, keepdim=True).values
+    zs = torch.sort(z, dim=-1, descending=True).values
+    rng = torch.arange(1, z.shape[-1] + 1, dtype=z.dtype, device=z.device).expand_as(z)
+    bound = 1 + rng * zs
+    is_gt = (bound > torch.cumsum(zs, dim=-1)).to(z.dtype)
+    k = (is_gt * rng).max(dim=-1, keepdim=True).values
+    taus = ((is_gt * zs).sum(dim=-1, keepdim=True) - 1) / k
+    return torch.max(torch.zeros_like(z), z - taus)
+
+
 def head_forward_heatmap(sd, x, *, n_deconv: int, final_kernel: int = 1,
                          temperature: float = 0.5, normalize=None, prefix: str = ""):
     """head.py:513-534 with deconv stack head.py:433-474 (k4 s2 p1, no bias)."""
@@ -263,8 +282,8 @@ def head_forward_heatmap(sd, x, *, n_deconv: int, final_kernel: int = 1,
                  padding=final_kernel // 2)                       # :227-233,525
     B, C, H, W = x.shape
     x = x.reshape(B, C, H * W) / temperature                      # :527-528
-    if normalize is not None:
-        raise NotImplementedError("Sparsemax path: sparsemax==0.1.9 absent, parity unpinned")
+    if normalize is not None:                                     # :528-530 (parity unpinned, see sparsemax_lastdim)
+        x = sparsemax_lastdim(x) * normalize
     return torch.clamp(x, 0, 1).reshape(B, C, H, W)               # :531-532
 
 
@@ -282,10 +301,11 @@ def head_forward_aux(sd, x, name: str, pools: Sequence, last: str, prefix: str =
 
 
 def head_forward(sd, feats, *, pools, n_deconv: int = 2, final_kernel: int = 1,
-                 prefix: str = ""):
+                 prefix: str = "", normalize=None):
     """ProbMapHead.forward (eval).  head.py:487-511."""
     return (
-        head_forward_heatmap(sd, feats, n_deconv=n_deconv, final_kernel=final_kernel, prefix=prefix),
+        head_forward_heatmap(sd, feats, n_deconv=n_deconv, final_kernel=final_kernel, prefix=prefix,
+                             normalize=normalize),
         head_forward_aux(sd, feats, "probability", pools, "sigmoid", prefix),
         head_forward_aux(sd, feats, "visibility", pools, "sigmoid", prefix),
         head_forward_aux(sd, feats, "oks", pools, "sigmoid", prefix),
@@ -293,10 +313,10 @@ def head_forward(sd, feats, *, pools, n_deconv: int = 2, final_kernel: int = 1,
     )
 
 
-def model_forward(sd, x, *, patch: int, heads: int, pools, n_deconv: int = 2):
+def model_forward(sd, x, *, patch: int, heads: int, pools, n_deconv: int = 2, normalize=None):
     """ProbPoseModel.forward = head(backbone(x)).  model.py:10-11."""
     feats = backbone_forward(sd, x, patch=patch, heads=heads, prefix="backbone.model.")
-    return head_forward(sd, feats, pools=pools, n_deconv=n_deconv, prefix="head.")
+    return head_forward(sd, feats, pools=pools, n_deconv=n_deconv, prefix="head.", normalize=normalize)
 
 
 # --------------------------------------------------------------------------

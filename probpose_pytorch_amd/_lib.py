@@ -12,7 +12,7 @@ PP_F32, PP_BF16, PP_FP8 = 0, 1, 2
 PP_MAX_RADIUS = 9
 PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS, EPI_HEATMAP = 1, 2, 4, 8, 16, 32, 64
-EPI_ROWSTATS, EPI_LNFOLD, EPI_OUT_FP8 = 128, 256, 512
+EPI_ROWSTATS, EPI_LNFOLD, EPI_OUT_FP8, EPI_NOCLAMP = 128, 256, 512, 1024
 
 _lock = threading.Lock()
 _lib = None
@@ -55,6 +55,8 @@ _SIGNATURES = {
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pp_final_heatmap": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "pp_final_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "pp_sparsemax_rows": (C.c_int, [_vp, C.c_longlong, _i, _f, _vp]),
     "pp_aux_tail": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_tokens_to_nchw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_nchw_to_tokens": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),

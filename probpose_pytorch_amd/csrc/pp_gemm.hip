@@ -98,6 +98,10 @@ struct GemmParams {
 // prefetch behind the MFMAs.  The asm DMA is invisible to its wait-count bookkeeping; completion is
 // enforced by the explicit s_waitcnt vmcnt(0) + barrier that ends each K-step.
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_off_uniform) {
+#ifdef PP_ABL_NODMA   // ablation builds only (tools/build_lab.sh): no staging traffic, results are garbage
+  asm volatile("" ::"v"(gsrc), "s"(lds_off_uniform));
+  return;
+#endif
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -166,14 +170,27 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // issue MFMAs, plus NWP producer waves that only issue the LDS-DMA pieces.  A global_load_lds
 // blocks its wave for ~100-200 cycles while the CU's address unit drains (measured); with the DMA
 // on the MFMA-issuing waves that stall came straight out of the matrix pipe's issue time.
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0, int LN = 0>
-__global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_kernel(GemmParams p) {
+//
+// PINGPONG (8 waves, 3 stages): the two waves that share a SIMD (w and w + 4) run the K-tile interval in
+// opposite order.  Waves 0-3: read the whole K-tile's fragments into registers, issue their DMA pieces, then
+// TM*TN*2 bare MFMAs.  Waves 4-7: the MFMAs of the fragments read in the PREVIOUS interval first, then the
+// fragment reads and DMA pieces for the next one.  One barrier per K-tile as before; between two barriers each
+// SIMD always has one wave in its matrix segment and the other in its LDS / DMA segment (in the plain form both
+// partners reach their DMA pieces together and the matrix pipe idles while the address unit drains).
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0, int LN = 0,
+          bool PINGPONG = false>
+__global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 < 2 ? 2 : (WGM * WGN + NWP + 3) / 4) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PP_GEMM_TIMELINE   // diagnostic build: wall-clock (100 MHz) marks per wave + where it ran
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+  unsigned long long rt_loop0 = 0, rt_loop1 = 0;
+#endif
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = ROW_BYTES / ES;  // elements of K per tile
   constexpr int NW = WGM * WGN;                         // consumer (MFMA) waves
   constexpr int NWS = NWP > 0 ? NWP : NW;               // waves that issue the DMA
   constexpr int NTHREADS = 64 * (NW + NWP);
+  constexpr int NTHREADS_EPI = 64 * NW;   // producer waves have exited by then
   constexpr int PA = BM / 8 / NWS, PB = BN / 8 / NWS;  // 1-KiB DMA pieces (8 rows) per staging wave per K-tile
   constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;  // 16x16 MFMA tiles per wave
   constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
@@ -395,10 +412,26 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 #ifdef PP_EXP_SETPRIO
               __builtin_amdgcn_s_setprio(1);
 #endif
+#if defined(PP_ABL_NOMMA)     // ablation: fragment reads stay (kept alive), no matrix work
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const unsigned k0 = bf[j].x ^ af[i].x, k1 = bf[j].y ^ af[i].y, k2 = bf[j].z ^ af[i].z,
+                               k3 = bf[j].w ^ af[i].w;
+                asm volatile("" ::"v"(k0), "v"(k1), "v"(k2), "v"(k3));
+              }
+#elif defined(PP_ABL_NOLDS)   // ablation: matrix work on whatever the registers hold, no fragment reads
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                bf16x8 za = {}, zb = {};
+                asm volatile("" : "+v"(za), "+v"(zb));
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zb, za, acc[i][j], 0, 0, 0);
+              }
+#else
 #pragma unroll
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
+#endif
 #ifdef PP_EXP_SETPRIO
               __builtin_amdgcn_s_setprio(0);
 #endif
@@ -429,6 +462,72 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     }(std::make_integer_sequence<int, 2>{});
   };
 
+  // ---- ping-pong form: a whole K-tile of fragments in registers (2 x (TM + TN) x 16 B per lane)
+  uint4 pfa[PINGPONG ? 2 : 1][PINGPONG ? TM : 1], pfb[PINGPONG ? 2 : 1][PINGPONG ? TN : 1];
+  // per-lane fragment offsets inside a stage: row (w? * tile + frow), chunk (4s + fq) ^ (row & 7); the row-tile
+  // index i / j only adds a multiple of 16 rows (an immediate offset of the ds_read, (row & 7) unchanged)
+  unsigned pp_offA[2], pp_offB[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    pp_offA[s] = (wm * (BM / WGM) + frow) * ROW_BYTES + (((4 * s + fq) ^ (frow & 7)) << 4);
+    pp_offB[s] = A_BYTES + (wn * (BN / WGN) + frow) * ROW_BYTES + (((4 * s + fq) ^ (frow & 7)) << 4);
+  }
+  auto pp_load = [&](int buf) {
+    const char *sb = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const char *pa = sb + pp_offA[s];
+      const char *pb = sb + pp_offB[s];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) pfa[s][i] = *reinterpret_cast<const uint4 *>(pa + i * 16 * ROW_BYTES);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) pfb[s][j] = *reinterpret_cast<const uint4 *>(pb + j * 16 * ROW_BYTES);
+    }
+  };
+  auto pp_mma = [&]() {
+#ifdef PP_MMA_PRIO
+    __builtin_amdgcn_s_setprio(PP_MMA_PRIO);
+#endif
+    if constexpr (ES == 1) {
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      constexpr int UNIT = 0x7f7f7f7f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const i32x8 av = {(int)pfa[0][i].x, (int)pfa[0][i].y, (int)pfa[0][i].z, (int)pfa[0][i].w,
+                          (int)pfa[1][i].x, (int)pfa[1][i].y, (int)pfa[1][i].z, (int)pfa[1][i].w};
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const i32x8 bv = {(int)pfb[0][j].x, (int)pfb[0][j].y, (int)pfb[0][j].z, (int)pfb[0][j].w,
+                            (int)pfb[1][j].x, (int)pfb[1][j].y, (int)pfb[1][j].z, (int)pfb[1][j].w};
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bv, av, acc[i][j], 0, 0, 0, UNIT, 0, UNIT);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if constexpr (ES == 2) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8 *>(&pfb[s][j]),
+                                                                  *reinterpret_cast<bf16x8 *>(&pfa[s][i]), acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    __uint_as_float(reinterpret_cast<const unsigned *>(&pfb[s][j])[e]),
+                    __uint_as_float(reinterpret_cast<const unsigned *>(&pfa[s][i])[e]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+#ifdef PP_MMA_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+
   // ---- pipeline fill first: the DMA of the first STAGES-1 K-tiles is in flight while the epilogue
   // operands below (residual / bias / LayerNorm statistics) are fetched and reduced.  Those loads are
   // YOUNGER than the fill, so the first counted wait of the K-loop over-waits (it also retires tile 1):
@@ -437,6 +536,33 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nkt) stage_all(s, s);
+  }
+
+  // ---- wave-specialised form: the producer waves run their whole K-loop here and EXIT (s_barrier counts only the
+  // surviving waves of a workgroup), so the accumulators, fragments and epilogue operands below are live in the
+  // consumer waves only and the register allocation is not the union of both roles.
+  if constexpr (NWP > 0) {
+    if (is_producer) {
+#pragma unroll
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nkt) stage_all(s, s);
+      int buf = 0;
+      for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + STAGES - 1 <= nkt) {
+          wait_vmcnt<(STAGES - 2) * PIECES>();
+        } else {
+          wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nkt) {
+          int nb = buf + STAGES - 1;
+          if (nb >= STAGES) nb -= STAGES;
+          stage_all(kt + STAGES - 1, nb);
+        }
+        if (++buf == STAGES) buf = 0;
+      }
+      return;
+    }
   }
 
   // ---- every additive epilogue term (bias, pos-embed row bias, the fp32 residual that the proj/fc2
@@ -558,29 +684,88 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
 #ifdef PP_GEMM_STAMPS
   unsigned long long t_pro_v = t_begin;
 #endif
-  if constexpr (NWP > 0) {
+  if constexpr (NWP > 0 && PINGPONG) {
+    // ---- wave-specialised form, software-pipelined consumer (one consumer wave per SIMD: nothing else hides its
+    // LDS latency).  MFMA groups of TN (one activation row-tile x all weight column tiles); while group g runs,
+    // the activation fragment of group g + 1 and a share of the NEXT k-step's weight fragments are already being
+    // read.  The barrier that publishes K-tile kt + 1 (and tells the producers that K-tile kt has been read: they
+    // overwrite its buffer next) sits in front of the LAST group of K-tile kt, right after the last fragment read
+    // of that tile has landed, so the first fragments of K-tile kt + 1 are in flight under that group's MFMAs.
+    static_assert(ES == 2, "pipelined consumer: bf16");
+    constexpr int BPG = (TN + TM - 1) / TM;   // next-step weight fragments read per group
+    uint4 Bc[TN], Bn[TN], Ac, An;
+    auto ldA = [&](int buf, int s, int i) {
+      return *reinterpret_cast<const uint4 *>(smem + buf * STAGE_BYTES + pp_offA[s] + i * 16 * ROW_BYTES);
+    };
+    auto ldB = [&](int buf, int s, int j) {
+      return *reinterpret_cast<const uint4 *>(smem + buf * STAGE_BYTES + pp_offB[s] + j * 16 * ROW_BYTES);
+    };
+    auto group = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8 *>(&Bc[j]),
+                                                            *reinterpret_cast<bf16x8 *>(&Ac), acc[i][j], 0, 0, 0);
+    };
+    auto ktile = [&](int buf, int nb, auto lastc) {
+      constexpr bool LAST = decltype(lastc)::value;
+      // k-step 0: read the k-step-1 fragments of this K-tile underneath
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+          constexpr int i = I;
+          An = (i + 1 < TM) ? ldA(buf, 0, i + 1) : ldA(buf, 1, 0);
+#pragma unroll
+          for (int j = i * BPG; j < (i + 1) * BPG && j < TN; ++j) Bn[j] = ldB(buf, 1, j);
+          __builtin_amdgcn_sched_barrier(0);
+          group(std::integral_constant<int, i>{});
+          __builtin_amdgcn_sched_barrier(0);
+          Ac = An;
+        }(), ...);
+      }(std::make_integer_sequence<int, TM>{});
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Bc[j] = Bn[j];
+      // k-step 1: the last group carries the barrier and the first reads of the next K-tile
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+          constexpr int i = I;
+          if constexpr (i + 1 < TM) {
+            An = ldA(buf, 1, i + 1);
+          } else if constexpr (!LAST) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            An = ldA(nb, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Bn[j] = ldB(nb, 0, j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          group(std::integral_constant<int, i>{});
+          __builtin_amdgcn_sched_barrier(0);
+          Ac = An;
+        }(), ...);
+      }(std::make_integer_sequence<int, TM>{});
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Bc[j] = Bn[j];
+      }
+    };
+    __builtin_amdgcn_s_barrier();                       // K-tile 0 has landed
+    __builtin_amdgcn_sched_barrier(0);
+    Ac = ldA(0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) Bc[j] = ldB(0, 0, j);
+    An = Ac;
+    int buf = 0;
+    for (int kt = 0; kt + 1 < nkt; ++kt) {
+      const int nb = buf + 1 == STAGES ? 0 : buf + 1;
+      ktile(buf, nb, std::false_type{});
+      buf = nb;
+    }
+    ktile(buf, 0, std::true_type{});
+  } else if constexpr (NWP > 0) {
     // ---- wave-specialised K-loop: same barrier protocol, the two halves of each iteration on
     // different waves.  Every wave executes exactly nkt barriers.
-    if (is_producer) {
-#pragma unroll
-      for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nkt) stage_all(s, s);
-      int buf = 0;
-      for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + STAGES - 1 <= nkt) {
-          wait_vmcnt<(STAGES - 2) * PIECES>();
-        } else {
-          wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        if (kt + STAGES - 1 < nkt) {
-          int nb = buf + STAGES - 1;
-          if (nb >= STAGES) nb -= STAGES;
-          stage_all(kt + STAGES - 1, nb);
-        }
-        if (++buf == STAGES) buf = 0;
-      }
-    } else {
+    {
       int buf = 0;
       for (int kt = 0; kt < nkt; ++kt) {
         PP_STAMP(tb);
@@ -595,10 +780,115 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
       }
     }
   } else {
-  // the loads above (bias, row map) are older than every DMA piece: retire them once, here, so that
-  // inside the loop only DMA pieces are outstanding and the counted waits are exact
+  // The epilogue operands above (residual / row bias into the accumulators, bias, row map) are ordinary global
+  // loads whose first USE is inside the K-loop (the accumulators are MFMA operands).  hipcc does not see the
+  // inline-asm DMA, so left alone it puts its own `s_waitcnt vmcnt(0)` in front of the loop's first MFMA - in
+  // EVERY iteration (loop-carried scoreboard) - which drains the whole LDS-DMA prefetch ring each K-tile
+  // (found in the round-1 kernel's ISA: the counted vmcnt(PIECES) was followed by a compiler vmcnt(0)).
+  // Retire them once here with a wait the compiler models: from now on only DMA pieces are outstanding and
+  // the loop keeps nothing but the counted waits.  Cost: the first iteration also waits for K-tile 1.
+#ifndef PP_NO_PRELOOP_WAIT
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
 #ifdef PP_GEMM_STAMPS
   t_pro_v = stamp();
+#endif
+#ifdef PP_GEMM_TIMELINE
+  rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  if constexpr (PINGPONG) {
+    static_assert(STAGES == 3 && NW == 8, "ping-pong form: 8 waves, 3 LDS stages");
+    // interval kt (between two barriers) reads K-tile kt and prefetches K-tile kt + 2 into the buffer that
+    // interval kt - 1 read.  The two roles are whole separate loops (wave-uniform branch): one code path per
+    // loop body, every wave passes exactly nkt barriers.
+    const bool late = __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+    int buf = 0, kt = 0;
+    auto advance = [&]() { if (++buf == STAGES) buf = 0; };
+    auto nbuf = [&]() { int nb = buf + STAGES - 1; return nb >= STAGES ? nb - STAGES : nb; };
+    if (!late) {
+      for (; kt + 2 < nkt; ++kt) {
+        PP_STAMP(ta);
+        wait_vmcnt<PIECES>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(tb);
+        pp_load(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(tc);
+        stage_all(kt + 2, nbuf());
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(td);
+        pp_mma();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(te);
+        PP_ACC(c_bar, ta, tb);
+        PP_ACC(c_wait, tb, tc);
+        PP_ACC(c_stage, tc, td);
+        PP_ACC(c_comp, td, te);
+        advance();
+      }
+      for (; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) wait_vmcnt<PIECES>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        pp_load(buf);
+        pp_mma();
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+      }
+    } else {
+      // first interval: nothing to multiply yet
+      if (nkt > 1) wait_vmcnt<PIECES>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      pp_load(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      if (2 < nkt) stage_all(2, nbuf());
+      advance();
+      kt = 1;
+      for (; kt + 2 < nkt; ++kt) {
+        PP_STAMP(ta);
+        wait_vmcnt<PIECES>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(tb);
+        pp_mma();
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(tc);
+        pp_load(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(td);
+        stage_all(kt + 2, nbuf());
+        __builtin_amdgcn_sched_barrier(0);
+        PP_STAMP(te);
+        PP_ACC(c_bar, ta, tb);
+        PP_ACC(c_comp, tb, tc);
+        PP_ACC(c_wait, tc, td);
+        PP_ACC(c_stage, td, te);
+        advance();
+      }
+      for (; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) wait_vmcnt<PIECES>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        pp_mma();
+        __builtin_amdgcn_sched_barrier(0);
+        pp_load(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+      }
+      pp_mma();
+    }
+  } else {
+#ifdef PP_YOUNG_PRIO
+  // static priority for the second-dispatched half of an 8-wave workgroup (the arbitration losers on every SIMD)
+  if constexpr (NW == 8) {
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(PP_YOUNG_PRIO);
+  }
 #endif
   int buf = 0, kt = 0;
   // steady state: every iteration prefetches tile kt + STAGES - 1 (one code path in the loop body,
@@ -640,8 +930,15 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
     PP_ACC(c_comp, tc, te);
     if (++buf == STAGES) buf = 0;
   }
+#ifdef PP_YOUNG_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  }
   }
   PP_STAMP(t_loop);
+#ifdef PP_GEMM_TIMELINE
+  rt_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- epilogue.  The W fragment is the MFMA "A" operand and the activation fragment the "B"
   // operand, so a 16x16 accumulator tile holds C^T: lane (frow, fq) owns output row m = .. + frow and
@@ -733,7 +1030,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
         __syncthreads();
         constexpr int CPR = PBN * OES / 16;           // 16-B chunks per row
         const int ncols16 = max(0, min(CPR, (p.N - n0 - pass * PBN) * OES / 16));
-        for (int c = tid; c < BM * CPR; c += NTHREADS) {
+        for (int c = tid; c < BM * CPR; c += NTHREADS_EPI) {
           const int lr = c / CPR, cc = c - lr * CPR;
           const int r = rows_lds[lr];
           if (r < 0 || cc >= ncols16) continue;
@@ -743,7 +1040,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
       }
       if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {   // one partial (sum, sum of squares) per row for this column tile
         __syncthreads();
-        for (int lr = tid; lr < BM; lr += NTHREADS) {
+        for (int lr = tid; lr < BM; lr += NTHREADS_EPI) {
           if (m0 + lr >= p.M) continue;
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -792,7 +1089,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
           __syncthreads();
           constexpr int CPR2 = PBN2 * ES2 / 16;
           const int ncols16 = max(0, min(CPR2, (p.N - n0 - pass * PBN2) * ES2 / 16));
-          for (int c = tid; c < BM * CPR2; c += NTHREADS) {
+          for (int c = tid; c < BM * CPR2; c += NTHREADS_EPI) {
             const int lr = c / CPR2, cc = c - lr * CPR2;
             const int r = rows2[lr];
             if (r < 0 || cc >= ncols16) continue;
@@ -854,7 +1151,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
         if (ne >= p.N) continue;
         float x = v[e];
         if (epi & PP_EPI_HEATMAP) {
-          x = fminf(fmaxf(x / p.hm_temperature, 0.f), 1.f);
+          x = x / p.hm_temperature;
+          if (!(epi & PP_EPI_NOCLAMP)) x = fminf(fmaxf(x, 0.f), 1.f);
           const int b = r / p.hm_HW, hw = r - b * p.hm_HW;
           reinterpret_cast<float *>(Cb)[((size_t)b * p.hm_K + ne) * p.hm_HW + hw] = x;
           continue;
@@ -868,6 +1166,18 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), NWP > 0 ? 3 : 2) void gemm_
       }
     }
   }
+#ifdef PP_GEMM_TIMELINE
+  if ((p.epilogue & (1 << 30)) && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile's stores have been accepted
+    const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
+                            ((size_t)blockIdx.x * NW + wave) * 8;
+    o[0] = rt_entry; o[1] = rt_loop0; o[2] = rt_loop1; o[3] = rt_end;
+    o[4] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+    o[5] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
+    o[6] = 1; o[7] = (unsigned long long)tm << 32 | (unsigned)tn;
+  }
+#endif
 #ifdef PP_GEMM_STAMPS
   if ((p.epilogue & (1 << 30)) && lane == 0) {
     PP_STAMP(t_end);
@@ -955,7 +1265,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
   // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 9, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 12, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -978,7 +1288,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   dim3 grid;
@@ -1004,18 +1314,24 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_REQUIRE(a->stats_parts == p.tiles_n, "pp_gemm: stats_parts=%d but this launch has %d column tiles",
                a->stats_parts, p.tiles_n);
   hipStream_t s = (hipStream_t)stream;
-#define PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_)                              \
+#define PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_)                         \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
     static thread_local bool attr = false;                                                            \
     if (!attr) {                                                                                      \
       PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
-          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_>), \
+          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
       attr = true;                                                                                    \
     }                                                                                                 \
-    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_>), grid,          \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_>), grid,     \
                        dim3(64 * (WGM_ * WGN_ + NWP_)), lds, s, p);                                   \
+  } while (0)
+#define PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_) PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, false)
+#define PP_LAUNCH_GEMM_PP(T, BM_, BN_, WGM_, WGN_, ST_)                                               \
+  do {                                                                                                \
+    if (gather) PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, true, true, 0, 0, true);               \
+    else PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, false, true, 0, 0, true);                     \
   } while (0)
 #define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_) PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, 0)
 #define PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_) PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, 0)
@@ -1033,16 +1349,26 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     p.tiles_n = cdiv(a->N, 192);
     set_grid(3);
   }
+#ifdef PP_GEMM_LAB   // experiment builds (tools/build_lab.sh): only the plain bf16 192x192 forms, compiles in seconds
+  if (a->dtype != PP_BF16 || gather || !vec || ln_mode || !(cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12))
+    return fail("pp_gemm (lab build): only plain bf16 tiles 3, 6, 10, 11 and 12");
+  if (cfg == 3) PP_LAUNCH_GEMM_V(bf16_t, 192, 192, 2, 4, 3, false, true);
+  else if (cfg == 6) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
+  else if (cfg == 12) PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 2, 3, false, true, 4, 0, true);
+  else if (cfg == 11) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, false, true, 4);
+  else PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 4, 3, false, true, 0, 0, true);
+#else
   if (a->dtype == PP_FP8) {
     PP_REQUIRE(vec && p.lds_epilogue, "pp_gemm: fp8 needs the vector / LDS epilogue path (aligned N, ldc, C)");
-    if (!(cfg == 2 || cfg == 3)) {
-      PP_REQUIRE(a->tile == 0, "pp_gemm: fp8 is built for tiles 2 and 3, got tile %d", cfg);
+    if (!(cfg == 2 || cfg == 3 || cfg == 10)) {
+      PP_REQUIRE(a->tile == 0, "pp_gemm: fp8 is built for tiles 2, 3 and 10, got tile %d", cfg);
       cfg = 3;
       p.tiles_m = cdiv(a->M, 192);
       p.tiles_n = cdiv(a->N, 192);
       set_grid(3);
     }
     if (cfg == 2) PP_LAUNCH_GEMM_V(fp8_t, 192, 96, 2, 2, 2, false, true);
+    else if (cfg == 10) PP_LAUNCH_GEMM_P(fp8_t, 192, 192, 2, 4, 3, false, true, 0, 0, true);
     else PP_LAUNCH_GEMM_V(fp8_t, 192, 192, 2, 4, 3, false, true);
   } else if (ln_mode) {
     // LayerNorm-fused instantiations exist for the plain (non-gather) 192x192 tile, and for consumers the 192x96 tile
@@ -1074,6 +1400,8 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 7) PP_LAUNCH_GEMM(bf16_t, 192, 384, 2, 4, 2);
     else if (cfg == 8) PP_LAUNCH_GEMM(bf16_t, 256, 256, 2, 4, 2);
     else if (cfg == 9) PP_LAUNCH_GEMM(bf16_t, 192, 256, 2, 4, 2);
+    else if (cfg == 10) PP_LAUNCH_GEMM_PP(bf16_t, 192, 192, 2, 4, 3);
+    else if (cfg == 11) { if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, true, true, 4); else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, false, true, 4); }
     else if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
   } else {
@@ -1084,12 +1412,17 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 5) PP_LAUNCH_GEMM(float, 384, 128, 2, 4, 2);
     else if (cfg == 7) PP_LAUNCH_GEMM(float, 192, 384, 2, 4, 2);
     else if (cfg == 8 || cfg == 9) return fail("pp_gemm: the 256-wide tiles are built for bf16 only (fp32 fragments do not fit the register file)");
+    else if (cfg == 10) PP_LAUNCH_GEMM_PP(float, 192, 192, 2, 4, 3);
+    else if (cfg == 11) return fail("pp_gemm: tile 11 (4 consumer + 4 producer waves) is built for bf16 only");
     else if (gather) PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, false, true, 4);
   }
+#endif
 #undef PP_LAUNCH_GEMM_V
 #undef PP_LAUNCH_GEMM_W
 #undef PP_LAUNCH_GEMM_L
+#undef PP_LAUNCH_GEMM_P
+#undef PP_LAUNCH_GEMM_PP
 #undef PP_LAUNCH_GEMM
   PP_CHECK_LAUNCH("gemm_kernel");
   return 0;

@@ -183,8 +183,13 @@ __global__ __launch_bounds__(256) void aux_tail_kernel(const T *__restrict__ x, 
 // that are 256-B contiguous per k) instead of a 128-wide MFMA tile that would be 87 % padding.
 // ---------------------------------------------------------------------------
 constexpr int FH_ROWS = 64;
+// CLAMP = false: the Sparsemax path (head.py:526 with normalize != None) takes the logits z / T unclamped
+template <bool CLAMP>
+__device__ __forceinline__ float fh_act(float v) {
+  return CLAMP ? fminf(fmaxf(v, 0.f), 1.f) : v;
+}
 
-template <typename T>
+template <typename T, bool CLAMP>
 __global__ __launch_bounds__(256) void final_heatmap_kernel(const T *__restrict__ x, const T *__restrict__ w,
                                                             const float *__restrict__ bias,
                                                             float *__restrict__ out, int M, int HW, int Cin,
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void final_heatmap_kernel(const T *__restrict_
 #pragma unroll
       for (int u = 0; u < KB; ++u) {
         const int k = kbase + 4 * u;
-        if (k < K) out[((size_t)b * K + k) * HW + hw] = fminf(fmaxf((acc[u] + bias[k]) / temperature, 0.f), 1.f);
+        if (k < K) out[((size_t)b * K + k) * HW + hw] = fh_act<CLAMP>((acc[u] + bias[k]) / temperature);
       }
     }
   }
@@ -253,7 +258,7 @@ typedef __bf16 fh_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float fh_f32x4 __attribute__((ext_vector_type(4)));
 constexpr int FHM_MAXKS = 16;   // Cin <= 512
 
-template <int NT>
+template <int NT, bool CLAMP>
 __global__ __launch_bounds__(256) void final_heatmap_mfma_kernel(const bf16_t *__restrict__ x,
                                                                  const bf16_t *__restrict__ w,
                                                                  const float *__restrict__ bias,
@@ -312,10 +317,10 @@ __global__ __launch_bounds__(256) void final_heatmap_mfma_kernel(const bf16_t *_
       const int n = j * 16 + row;
       if (n < K) {
         float4 o;
-        o.x = fminf(fmaxf((acc[j][0] + bn[j]) / temperature, 0.f), 1.f);
-        o.y = fminf(fmaxf((acc[j][1] + bn[j]) / temperature, 0.f), 1.f);
-        o.z = fminf(fmaxf((acc[j][2] + bn[j]) / temperature, 0.f), 1.f);
-        o.w = fminf(fmaxf((acc[j][3] + bn[j]) / temperature, 0.f), 1.f);
+        o.x = fh_act<CLAMP>((acc[j][0] + bn[j]) / temperature);
+        o.y = fh_act<CLAMP>((acc[j][1] + bn[j]) / temperature);
+        o.z = fh_act<CLAMP>((acc[j][2] + bn[j]) / temperature);
+        o.w = fh_act<CLAMP>((acc[j][3] + bn[j]) / temperature);
         *reinterpret_cast<float4 *>(out + ((size_t)b * K + n) * HW + hw) = o;
       }
     }
@@ -562,7 +567,8 @@ extern "C" int pp_aux_tail(const void *x, const void *w, const float *bias, floa
   return 0;
 }
 
-extern "C" int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B, int HW,
+template <bool CLAMP>
+static int final_heatmap_launch(const void *x, const void *w, const float *bias, float *out, int B, int HW,
                                 int Cin, int K, float temperature, int dtype, void *stream) {
   PP_REQUIRE(B >= 0 && HW > 0 && Cin > 0 && K > 0 && temperature != 0.f, "pp_final_heatmap: bad shape");
   if (B == 0) return 0;
@@ -581,9 +587,9 @@ extern "C" int pp_final_heatmap(const void *x, const void *w, const float *bias,
 #define PP_FHM(NT_)                                                                                       \
   do {                                                                                                    \
     if (lds_w > 64 * 1024)                                                                                \
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_mfma_kernel<NT_>),    \
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&final_heatmap_mfma_kernel<NT_, CLAMP>),    \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));          \
-    hipLaunchKernelGGL(final_heatmap_mfma_kernel<NT_>, dim3(grid), dim3(256), lds_w, sm, (const bf16_t *)x, \
+    hipLaunchKernelGGL((final_heatmap_mfma_kernel<NT_, CLAMP>), dim3(grid), dim3(256), lds_w, sm, (const bf16_t *)x, \
                        (const bf16_t *)w, bias, out, tiles, HW, Cin, K, temperature);                     \
   } while (0)
     if (nt <= 2) PP_FHM(2);
@@ -599,19 +605,29 @@ extern "C" int pp_final_heatmap(const void *x, const void *w, const float *bias,
   const int grid = cdiv(M, FH_ROWS);
   if (dtype == PP_BF16) {
     if (lds > 64 * 1024)
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_kernel<bf16_t>),
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_kernel<bf16_t, CLAMP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(final_heatmap_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, (const bf16_t *)x,
+    hipLaunchKernelGGL((final_heatmap_kernel<bf16_t, CLAMP>), dim3(grid), dim3(256), lds, s, (const bf16_t *)x,
                        (const bf16_t *)w, bias, out, (int)M, HW, Cin, K, temperature);
   } else {
     if (lds > 64 * 1024)
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_kernel<float>),
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(final_heatmap_kernel<float, CLAMP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(final_heatmap_kernel<float>, dim3(grid), dim3(256), lds, s, (const float *)x,
+    hipLaunchKernelGGL((final_heatmap_kernel<float, CLAMP>), dim3(grid), dim3(256), lds, s, (const float *)x,
                        (const float *)w, bias, out, (int)M, HW, Cin, K, temperature);
   }
   PP_CHECK_LAUNCH("final_heatmap_kernel");
   return 0;
+}
+
+extern "C" int pp_final_heatmap(const void *x, const void *w, const float *bias, float *out, int B, int HW,
+                                int Cin, int K, float temperature, int dtype, void *stream) {
+  return final_heatmap_launch<true>(x, w, bias, out, B, HW, Cin, K, temperature, dtype, stream);
+}
+
+extern "C" int pp_final_logits(const void *x, const void *w, const float *bias, float *out, int B, int HW,
+                               int Cin, int K, float temperature, int dtype, void *stream) {
+  return final_heatmap_launch<false>(x, w, bias, out, B, HW, Cin, K, temperature, dtype, stream);
 }
 
 extern "C" int pp_tokens_to_nchw(const void *x, float *out, int B, int N, int C, int dtype, void *stream) {

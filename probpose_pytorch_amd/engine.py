@@ -313,10 +313,9 @@ class HeadPlan:
         self.K = head.out_channels
         self.C = head.in_channels
         self.temperature = float(head.temperature)
-        if not isinstance(head.normalize_layer, nn.Identity) or head.normalize is not None:
-            raise NotImplementedError(
-                "normalize != None (Sparsemax, sparsemax==0.1.9) has no oracle in the reference "
-                "checkout (parity unpinned) and is not built")
+        # normalize != None: Sparsemax over H*W, * normalize, clamp (head.py:237-245,526-532) as pp_sparsemax_rows on
+        # the unclamped logits; the third-party library is not in the reference checkout -> parity unpinned
+        self.normalize = None if head.normalize is None else float(head.normalize)
         # --- heatmap branch: deconvs (+BN+ReLU), optional convs (+BN+ReLU), final conv
         self.deconvs = []
         cin = self.C
@@ -473,11 +472,14 @@ class HeadPlan:
         f = self.final
         kk = f["k"] * f["k"]
         es = 2 if dt == torch.bfloat16 else 4
+        clamp = self.normalize is None
         if f["k"] == 1 and 64 * (cin * es + 16) + K * cin * es <= 150 * 1024:
-            ops.final_heatmap(x, f["w"], f["b"], heat, B, hh * ww, cin, K, self.temperature)
+            ops.final_heatmap(x, f["w"], f["b"], heat, B, hh * ww, cin, K, self.temperature, clamp=clamp)
         else:
             ops.gemm(x, f["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=f["b"],
-                     rowoff=tb["final"], seg_len=cin, heatmap=(K, hh * ww, self.temperature))
+                     rowoff=tb["final"], seg_len=cin, heatmap=(K, hh * ww, self.temperature, clamp))
+        if not clamp:
+            ops.sparsemax_rows(heat.view(B * K, hh * ww), self.normalize)
         # ---- join the aux-branch stream (forked above)
         torch.cuda.current_stream(dev).wait_stream(aux_stream)
         return (heat, aux[0].reshape(B, K, 1, 1), aux[1].reshape(B, K, 1, 1), aux[2].reshape(B, K, 1, 1),

@@ -17,6 +17,24 @@ from . import _lib, engine, ops
 from .pack import deconv_geometry
 
 
+class Sparsemax(nn.Module):
+    """Stand-in for ``sparsemax.Sparsemax(dim=-1)`` (head.py:11,241; third-party sparsemax==0.1.9, not part of the
+    reference checkout): holds no parameters, so state_dicts are unchanged.  The HIP head applies the projection
+    itself (``pp_sparsemax_rows``: Martins & Astudillo 2016, parity unpinned); calling the module directly runs the
+    same kernel on a contiguous float32 GPU tensor."""
+
+    def __init__(self, dim: int = -1):
+        super().__init__()
+        if dim != -1:
+            raise ValueError("the HIP Sparsemax normalises the last axis (the reference uses dim=-1, head.py:241)")
+        self.dim = dim
+
+    def forward(self, x: Tensor) -> Tensor:
+        _lib.require_device(x)
+        out = x.detach().float().contiguous().clone()
+        return ops.sparsemax_rows(out, 1.0)      # sparsemax lies in [0, 1]: with scale 1 the kernel's clamp is idle
+
+
 class ProbMapHead(nn.Module):
     def __init__(
         self,
@@ -86,7 +104,7 @@ class ProbMapHead(nn.Module):
         if normalize is None:
             self.normalize_layer = nn.Identity()
         else:
-            raise ImportError("Sparsemax is not installed. Please install sparsemax to use this feature.")
+            self.normalize_layer = Sparsemax(dim=-1)
 
         # ---- aux branches (head.py:255-405)
         def aux(last):

@@ -36,7 +36,7 @@ def _tol(dtype, out_dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (192, 768, 768), (300, 200, 128), (1, 17, 256), (257, 129, 64),
                                    (384, 2304, 768), (192, 96, 64), (193, 97, 128), (400, 400, 3072)])
 def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
@@ -80,7 +80,7 @@ def test_gemm_exact_integer_data_catches_layout_bugs(ops, dtype):
     g = torch.Generator().manual_seed(0)
     A = torch.randint(-3, 4, (M, K), generator=g).to(dtype).cuda()
     W = torch.randint(-3, 4, (N, K), generator=g).to(dtype).cuda()
-    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10):
         if tile == 8 and dtype == torch.float32:
             continue
         out = ops.linear(A, W, out_dtype=torch.float32, tile=tile)
@@ -102,7 +102,7 @@ def test_gemm_conv3x3_gather_batched_branches(ops, dtype):
     Wp = torch.stack([pack.conv_taps_major(wt[i].cpu()) for i in range(4)]).to(dtype).cuda()
     ro = pack.conv_gather_table(B, h, w, 3, 3, 1, 1, 4 * C).cuda()
     out = torch.empty((B * h * w, 4 * C), dtype=dtype, device="cuda")
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 10):
         if tile == 8 and dtype == torch.float32:
             continue
         out.zero_()
@@ -120,7 +120,7 @@ def _check_branches(x, Wp, bias, out, B, h, w, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("k", [4, 3, 2])
 def test_gemm_deconv_parities_scatter(ops, dtype, k, tile):
     from probpose_pytorch_amd import pack
@@ -316,7 +316,7 @@ def _fp8_case(M, N, K, seed):
     return a8.cuda(), w8.cuda(), cs.cuda(), bias.cuda(), ref
 
 
-@pytest.mark.parametrize("tile", [0, 2, 3])
+@pytest.mark.parametrize("tile", [0, 2, 3, 10])
 @pytest.mark.parametrize("M,N,K", [(192, 192, 128), (500, 384, 768), (1000, 96, 256), (77, 776, 384)])
 def test_gemm_fp8_bf16_out(ops, M, N, K, tile):
     a8, w8, cs, bias, ref = _fp8_case(M, N, K, 11)

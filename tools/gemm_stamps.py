@@ -13,7 +13,12 @@ import torch
 from probpose_pytorch_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-L = C.CDLL(os.path.join(ROOT, "probpose_pytorch_amd", "lib", "diag", "libpp_gemm_stamps.so"))
+LIBP = os.path.join(ROOT, "probpose_pytorch_amd", "lib", "diag", "libpp_gemm_stamps.so")
+if "--lib" in sys.argv:
+    i = sys.argv.index("--lib")
+    LIBP = os.path.join(ROOT, "probpose_pytorch_amd", "lib", "exp", sys.argv[i + 1])
+    del sys.argv[i:i + 2]
+L = C.CDLL(LIBP)
 L.pp_gemm.restype = C.c_int
 L.pp_gemm.argtypes = [C.POINTER(_lib.GemmArgs), C.c_void_p]
 L.pp_last_error.restype = C.c_char_p
@@ -37,11 +42,20 @@ for _ in range(3):
     rc = L.pp_gemm(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, L.pp_last_error()
 torch.cuda.synchronize()
-s = stamps.cpu().numpy().reshape(-1, 8)
-s = s[s[:, 6] > 0]
+s_all = stamps.cpu().numpy().reshape(-1, 8, 8)          # [workgroup, wave, field]
 names = ["prologue", "vmcnt wait", "barrier", "stage issue", "compute", "epilogue", "total"]
-print(f"M={M} N={N} K={K} tile={tile}: {len(s)} waves stamped, K-tiles = {K // 64}")
-for i, n in enumerate(names):
-    print(f"  {n:12s} mean {s[:, i].mean():10.0f} cycles  ({100 * s[:, i].mean() / s[:, 6].mean():5.1f} %)   p50 {np.median(s[:, i]):9.0f}")
+if tile == 10:   # ping-pong: fields are frag-read issue / wait+barrier / DMA issue / MFMA, per wave role
+    names = ["prologue", "frag reads", "wait+barrier", "DMA issue", "MFMA", "epilogue", "total"]
+print(f"M={M} N={N} K={K} tile={tile}: K-tiles = {K // 64}")
+for role, sl in (("waves 0-3", slice(0, 4)), ("waves 4-7", slice(4, 8))):
+    s = s_all[:, sl].reshape(-1, 8)
+    s = s[s[:, 6] > 0]
+    if not len(s):
+        continue
+    print(f" {role}: {len(s)} waves stamped")
+    for i, n in enumerate(names):
+        print(f"  {n:12s} mean {s[:, i].mean():10.0f} cycles  ({100 * s[:, i].mean() / s[:, 6].mean():5.1f} %)   p50 {np.median(s[:, i]):9.0f}")
+s = s_all.reshape(-1, 8)
+s = s[s[:, 6] > 0]
 span = s[:, 7].max() + s[s[:, 7].argmax(), 6] - s[:, 7].min()
 print(f"  kernel span {span} cycles (s_memtime)")
