@@ -121,40 +121,93 @@ def build(cfg, dtype, device):
     return model, codec, sd
 
 
-def cpu_baseline(cfg, sd, seconds_budget: float = 20.0):
-    """The reference's CPU path (restated in oracle/, pinned on the reference's goldens): plain PyTorch
-    fp32 eval forward + per-crop scipy decode, timed on this host's cores on a bounded sample."""
+def _cpu_pass(orc, sd, cfg, x, sig):
+    """One forward + decode pass of the CPU path; returns (forward s, decode s)."""
+    H, W = cfg["img"]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = orc.model_forward(sd, x, patch=16, heads=cfg["heads"], pools=cfg["pools"])
+    t1 = time.perf_counter()
+    orc.codec_decode([o.numpy() for o in out], (W, H), (W // 4, H // 4), sig)
+    return t1 - t0, time.perf_counter() - t1
+
+
+def cpu_baseline(cfg, sd, seconds_budget: float = 18.0):
+    """The reference's CPU path (restated in oracle/, pinned on the reference's goldens): plain PyTorch fp32 eval
+    forward + per-crop scipy decode on this host's cores.  BASELINE.md section 3: median of 5 passes after 2
+    warm-ups over a bounded sample of the bench workload, forward and decode ms/crop from the SAME passes, plus the
+    S1 line (ViT-S, one crop: forward + decode latency)."""
     from oracle import probpose_oracle as orc
-    from probpose_pytorch_amd.synthetic import synthetic_crops
+    from probpose_pytorch_amd.synthetic import synthetic_crops, synthetic_model_state
     H, W = cfg["img"]
     cores = torch.get_num_threads()
     sig = sigmas_for(cfg["K"])
-
-    def run(x):
-        with torch.no_grad():
-            out = orc.model_forward(sd, x, patch=16, heads=cfg["heads"], pools=cfg["pools"])
-        return orc.codec_decode([o.numpy() for o in out], (W, H), (W // 4, H // 4), sig)
-
-    x1 = synthetic_crops(2, H, W, seed=99)
-    t0 = time.perf_counter()
-    run(x1)                                   # warm-up + calibration
-    per_crop = (time.perf_counter() - t0) / 2
-    n = int(max(2, min(64, seconds_budget / max(per_crop, 1e-3))))
+    f, d = _cpu_pass(orc, sd, cfg, synthetic_crops(2, H, W, seed=99), sig)     # calibration (also a warm-up)
+    per_crop = (f + d) / 2
+    n = int(max(2, min(cfg["batch"], seconds_budget / 7 / max(per_crop, 1e-3))))
     x = synthetic_crops(n, H, W, seed=1234)
-    t0 = time.perf_counter()
-    out = run(x)
-    dt = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    passes = [_cpu_pass(orc, sd, cfg, x, sig) for _ in range(7)][2:]             # 2 warm-ups, 5 timed
+    tot = sorted(f_ + d_ for f_, d_ in passes)[2]
+    fwd = sorted(f_ for f_, _ in passes)[2]
+    dec = sorted(d_ for _, d_ in passes)[2]
+    # S1 (BASELINE.json configs[0]): single 256x192 crop, ViT-S (C 384, depth 12, 12 heads), K = 17
+    s1 = dict(CONFIGS["vit_s"])
+    sd1 = synthetic_model_state(s1["img"], 16, s1["C"], s1["depth"], s1["K"], len(s1["pools"]), (256, 256), seed=0)
+    x1 = synthetic_crops(1, *s1["img"], seed=7)
+    sig1 = sigmas_for(s1["K"])
+    p1 = [_cpu_pass(orc, sd1, s1, x1, sig1) for _ in range(7)][2:]
+    return {"value": round(n / tot, 3), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"{n} crops of the bench workload, torch fp32 CPU eval forward + per-crop scipy decode "
+                      f"(oracle/probpose_oracle.py); median of 5 passes after 2 warm-ups",
+            "forward_ms_per_crop": round(fwd / n * 1e3, 2), "decode_ms_per_crop": round(dec / n * 1e3, 3),
+            "s1_vit_s_single_crop": {"forward_ms": round(sorted(f_ for f_, _ in p1)[2] * 1e3, 2),
+                                     "decode_ms": round(sorted(d_ for _, d_ in p1)[2] * 1e3, 2),
+                                     "latency_ms": round(sorted(f_ + d_ for f_, d_ in p1)[2] * 1e3, 2),
+                                     "runs": "median of 5 after 2 warm-ups"}}
+
+
+def parity_block(cfg, sd, model, codec, x, dtype, n_crops: int = 8, fp32_steps: int = 3):
+    """What the benchmarked dtype costs in accuracy and what the contract-meeting mode costs in speed
+    (BASELINE.json north_star: decoded keypoints / probabilities within 1e-4 of the CPU path -- met by the
+    exact-fp32 MFMA mode; bf16 / fp8 report their measured deviation).  The reference here is
+    oracle.model_forward + codec_decode on the same crops (checker only, never the thing measured)."""
+    from oracle import probpose_oracle as orc
+    H, W = cfg["img"]
+    sig = sigmas_for(cfg["K"])
+    xs = x[:n_crops]
     with torch.no_grad():
-        hm = orc.model_forward(sd, x[:2], patch=16, heads=cfg["heads"], pools=cfg["pools"])
-    fwd2 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.codec_decode([o.numpy() for o in hm], (W, H), (W // 4, H // 4), sig)
-    dec_ms = (time.perf_counter() - t0) / 2 * 1e3
-    return {"value": round(n / dt, 3), "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"{n} crops, torch fp32 CPU eval forward + per-crop scipy decode (oracle/probpose_oracle.py), "
-                      f"one pass after a 2-crop warm-up", "decode_ms_per_crop": round(dec_ms, 3),
-            "forward_ms_per_crop": round(fwd2 / 2 * 1e3, 2)}
+        ref_out = orc.model_forward(sd, xs.cpu(), patch=16, heads=cfg["heads"], pools=cfg["pools"])
+    ref = orc.codec_decode([o.numpy() for o in ref_out], (W, H), (W // 4, H // 4), sig)
+
+    def deviation(out):
+        dec = codec.decode(out)
+        d = np.abs(dec[0][0] - ref[0][0]).max(-1)               # per keypoint, input pixels
+        hm = (out[0].float().cpu() - ref_out[0]).abs()
+        return {"kpt_px_median": round(float(np.median(d)), 6), "kpt_px_p90": round(float(np.percentile(d, 90)), 6),
+                "kpt_px_max": round(float(d.max()), 6),
+                "frac_kpts_within_1e-4_px": round(float((d <= 1e-4).mean()), 4),
+                "peak_moved_rate": round(float((d > 2.0).mean()), 4),      # > half a heatmap cell (4 input px)
+                "heatmap_abs_mean": round(float(hm.mean()), 7), "heatmap_abs_max": round(float(hm.max()), 6),
+                "aux_abs_max": round(max(float(np.abs(a - b).max()) for a, b in zip(dec[1:], ref[1:])), 7)}
+
+    res = {"reference": f"oracle.model_forward + codec_decode (CPU fp32) on the first {n_crops} crops of the batch",
+           "contract": "<= 1e-4 abs (north_star); flips between near-tied pixels of the random-weight heatmaps "
+                       "are counted in peak_moved_rate (see tests/test_model_gpu.py)"}
+    with torch.no_grad():
+        res[{torch.bfloat16: "bf16", torch.float32: "fp32"}.get(dtype, "fp8")] = deviation(model(xs))
+        if dtype != torch.float32:
+            model.set_compute_dtype(torch.float32)
+            res["fp32"] = deviation(model(xs))
+            for _ in range(2):
+                codec.decode_device(model(x))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(fp32_steps):
+                codec.decode_device(model(x))
+            torch.cuda.synchronize()
+            res["fp32_mode_crops_per_s"] = round(x.shape[0] * fp32_steps / (time.perf_counter() - t0), 1)
+            model.set_compute_dtype(dtype)
+    return res
 
 
 def main():
@@ -167,6 +220,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (fp32-mode throughput + deviation "
+                                                              "of the decoded results from the CPU oracle on 8 crops)")
     ap.add_argument("--single-stream", action="store_true",
                     help="no second HIP stream for the aux branches: every kernel runs alone, so a kernel trace of "
                          "this run shows the kernels' own durations (what roofline.avg_launch_us is measured on)")
@@ -312,7 +367,7 @@ def main():
                        "gflop_per_crop": round(flops_per_crop(cfg) / 1e9, 2)},
             "decode_ms": round(d_t * 1e3, 4),
             "model_tflops": round(flops_per_crop(cfg) * crops_per_s / world / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel", "achieved": round(achieved, 2), "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (+ pp::gemm_persist_kernel where selected)", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": g_traffic,
                          "traffic_source": traffic_src, "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
                          "flop_per_launch": round(g_flops / max(g_n, 1), 0)},
@@ -329,6 +384,8 @@ def main():
             line["measured_device_peaks"] = mp
             if args.dtype == "bf16":
                 line["roofline"]["frac_of_measured_mfma"] = round(achieved / mp["mfma_bf16_random_tflops"], 4)
+        if world == 1 and not args.no_parity:
+            line["parity"] = parity_block(cfg, sd, model, codec, x, dtype)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(line))

@@ -1189,6 +1189,313 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of the 192x192 / 8-wave / 3-stage configuration for the plain bf16 -> bf16 layers (qkv, fc1).
+//
+// Measured on the per-launch form (tools/gemm_timeline.py, ViT-B bs 64): a workgroup lives 17-19 us per tile, of
+// which the K-loop is only 11.6 us; 2.6 us go to the pipeline fill (address set-up, the first two K-tiles' DMA
+// latency) and 3-5 us to the epilogue (GELU + 18.9 MB per round stored by all 256 CUs in the same phase), and one
+// workgroup per CU means nothing else runs on the CU meanwhile.  Here one workgroup per CU walks its tiles back to
+// back as ONE continuous stream of K-tiles through the LDS ring: the DMA of the next tile's first K-tiles is issued
+// during the current tile's last ones (no fill between tiles), and a finished tile stays in 72 registers
+// (fp32) and is biased / activated / packed / stored in 9 slices underneath the first 9 K-tiles of the NEXT tile
+// (VALU and the store path beside the matrix pipe).  The bias of a tile comes through LDS by one small DMA per
+// tile (no compiler-visible global loads inside the stream: hipcc would drain the DMA ring for them).  Only the
+// last tile of a workgroup pays an un-overlapped epilogue.  Stores are issued at the head of an iteration, before
+// that iteration's DMA pieces, so the counted vmcnt(PIECES) never waits for anything younger than one K-tile.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int vblocks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 192, BN = 192, WGN = 4, STAGES = 3, BK = 64;
+  constexpr int PA = 3, PB = 3, PIECES = PA + PB, TM = 6, TN = 3;
+  constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
+  constexpr int BIAS_OFF = STAGES * STAGE_BYTES, BIAS_SLOT = BN * 4;   // 3 slots of 192 floats behind the ring
+  constexpr int NSLICE = TM * TN / 2;                                    // deferred-epilogue slices (2 tiles each)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int prow = lane >> 3, pchunk = lane & 7, frow = lane & 15, fq = lane >> 4;
+  const int nkt = p.Kd / BK;
+  const int epi = p.epilogue;
+
+  // virtual block id -> tile, exactly the per-launch kernel's XCD-aware order (ids b and b + 8 share an XCD; the
+  // stride gridDim.x is a multiple of 8, so a workgroup's tiles keep its XCD's slice of the order)
+  auto decode = [&](int vb, int &tm, int &tn) __attribute__((always_inline)) -> bool {
+    if (p.blocked) {
+      constexpr int RM = 8;
+      const int RN = p.rn, RT = RM * RN;
+      const int nbm = (p.tiles_m + RM - 1) / RM, nbn = (p.tiles_n + RN - 1) / RN;
+      const int x = vb & 7, j = vb >> 3;
+      const int g = (j / RT) * 8 + x, idx = j % RT;
+      if (g >= nbm * nbn) return false;
+      const int bmi = g / nbn, bni = g - bmi * nbn;
+      tm = bmi * RM + idx / RN;
+      tn = bni * RN + idx % RN;
+      return tm < p.tiles_m && tn < p.tiles_n;
+    }
+    tm = vb / p.tiles_n;
+    tn = vb - tm * p.tiles_n;
+    return vb < p.tiles_m * p.tiles_n;
+  };
+  auto next_valid = [&](int vb) __attribute__((always_inline)) -> int {   // first valid id >= vb on this workgroup's stride, or -1
+    int tm, tn;
+    for (; vb < vblocks; vb += (int)gridDim.x)
+      if (decode(vb, tm, tn)) return vb;
+    return -1;
+  };
+  int ntiles = 0;
+  for (int vb = next_valid((int)blockIdx.x); vb >= 0; vb = next_valid(vb + (int)gridDim.x)) ++ntiles;
+  if (ntiles == 0) return;
+  const int total = ntiles * nkt;
+
+  const char *zero_line = (const char *)g_zero_page +
+                          ((((blockIdx.x * 29 + wave) * 8 + prow) & 7) * 128 + pchunk * 16) +
+                          (((blockIdx.x * 13 + wave * 5) & 7) * 8192);
+  const unsigned lds0 = lds_offset_of(smem);
+  const int lchunk_off = (pchunk ^ prow) * 16;
+
+  // ---- staging stream: the next K-tile to stage is (s_vb, s_kt)
+  int s_vb = next_valid((int)blockIdx.x), s_kt = 0, s_slot = 0, s_n0 = 0;
+  const char *a_src[PA];
+  const char *w_src[PB];
+  bool w_ok[PB];
+  auto stage_setup = [&]() __attribute__((always_inline)) {
+    int tm, tn;
+    decode(s_vb, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    s_n0 = n0;
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+      const int r = (wave * PA + j) * 8 + prow;
+      a_src[j] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda * 2 + lchunk_off;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+      const int r = n0 + (wave * PB + j) * 8 + prow;
+      w_ok[j] = r < p.N;
+      w_src[j] = w_ok[j] ? p.W + (size_t)r * p.ldw * 2 + lchunk_off : zero_line + ((j * 5 + 3) & 7) * 1024;
+    }
+  };
+  stage_setup();
+  unsigned st_ldsA = 0, st_ldsB = 0;
+  size_t st_koff = 0;
+  // Every iteration of the stream stages one K-tile, so that every iteration is the same straight-line code and
+  // the counted vmcnt(PIECES) holds to the end: once the workgroup's tiles are exhausted (the last two
+  // iterations) the pieces re-read the last K-tile into the buffer nobody will read again.
+  auto stage_begin = [&](int buf) __attribute__((always_inline)) {      // latch (s_vb, s_kt) for the pieces of this iteration
+    const bool st_live = s_vb >= 0;
+    st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
+    st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
+    st_koff = (size_t)s_kt * ROW_BYTES;
+    if (st_live && s_kt == 0 && wave == 0 && (epi & PP_EPI_BIAS)) {
+      // this tile's bias segment -> LDS slot (one 768-byte DMA by wave 0; lanes beyond N stay unwritten, never stored)
+      if (lane < BN / 4 && s_n0 + lane * 4 < p.N)
+        glds16(p.bias + s_n0 + lane * 4, __builtin_amdgcn_readfirstlane(lds0 + BIAS_OFF + s_slot * BIAS_SLOT));
+    }
+  };
+  auto stage_piece = [&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < PA) {
+      glds16(a_src[q] + st_koff, st_ldsA + q * 1024);
+    } else {
+      constexpr int j = q - PA;
+      glds16(w_ok[j] ? w_src[j] + st_koff : w_src[j], st_ldsB + j * 1024);
+    }
+  };
+  auto stage_end = [&]() __attribute__((always_inline)) {               // advance; crossing into the next tile re-derives the source rows
+    if (s_vb < 0) return;
+    if (s_kt + 1 == nkt) {
+      const int nv = next_valid(s_vb + (int)gridDim.x);
+      if (nv < 0) {          // exhausted: keep the sources of the last K-tile (dummy re-reads from here on)
+        s_vb = -1;
+        return;
+      }
+      s_vb = nv;
+      s_kt = 0;
+      s_slot = s_slot == 2 ? 0 : s_slot + 1;
+      stage_setup();
+    } else {
+      ++s_kt;
+    }
+  };
+  auto stage_all = [&](int buf) __attribute__((always_inline)) {
+    stage_begin(buf);
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      (stage_piece(std::integral_constant<int, Q>{}), ...);
+    }(std::make_integer_sequence<int, PIECES>{});
+    stage_end();
+  };
+
+  // acc: the tile being accumulated.  fin: the finished tile awaiting its activation + store, held as packed bf16 of
+  // (accumulator + bias) -- 36 registers instead of 72 (two fp32 tiles + fragments do not fit 256 VGPRs without
+  // spills, and a spill reload inside the stream costs a vmcnt(0)).  For layers without an activation this is the
+  // final value; with GELU the activation is applied to the bf16-rounded pre-activation (one extra rounding of
+  // <= 2^-9 relative on its argument, same order as the output's own bf16 rounding).
+  f32x4 acc[TM][TN];
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 fin[TM][TN];
+  constexpr int GROUPS = 2 * TM;
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const char *ldsA = smem + buf * STAGE_BYTES;
+    const char *ldsB = ldsA + A_BYTES;
+    [&]<int... S>(std::integer_sequence<int, S...>) {
+      ([&] {
+        constexpr int s = S;
+        uint4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ra = wm * (BM / 2) + i * 16 + frow;
+          af[i] = *reinterpret_cast<const uint4 *>(ldsA + ra * ROW_BYTES + (((4 * s + fq) ^ (ra & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int rb = wn * (BN / WGN) + j * 16 + frow;
+          bf[j] = *reinterpret_cast<const uint4 *>(ldsB + rb * ROW_BYTES + (((4 * s + fq) ^ (rb & 7)) << 4));
+        }
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+          ([&] {
+            constexpr int i = I;
+            constexpr int grp = s * TM + i;
+            [&]<int... Q>(std::integer_sequence<int, Q...>) {
+              ([&] {
+                if constexpr ((Q * GROUPS) / PIECES == grp) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  stage_piece(std::integral_constant<int, Q>{});
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }(), ...);
+            }(std::make_integer_sequence<int, PIECES>{});
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
+          }(), ...);
+        }(std::make_integer_sequence<int, TM>{});
+      }(), ...);
+    }(std::make_integer_sequence<int, 2>{});
+  };
+
+  // ---- deferred epilogue of the finished tile: accumulator tile q = (i, j), q a compile-time constant.
+  // The store is inline asm on purpose: hipcc counts its own stores in vmcnt and protects their data registers with
+  // vmcnt(N) waits that know nothing of the DMA pieces -- in the loop they drained the whole ring (seen in the ISA).
+  int prev_m0 = 0, prev_n0 = 0;
+  bool have_prev = false;
+  bf16_t *Cb = reinterpret_cast<bf16_t *>(p.C);
+  auto half_slice = [&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int i = q / TN, j = q % TN;
+    int m = prev_m0 + wm * (BM / 2) + i * 16 + frow;
+    // opaque: the 18 store addresses are loop-invariant inside a tile and LICM would hoist all of them (36
+    // registers + predicates) out of the K-loop, pushing the kernel into scratch; a volatile asm is never hoisted
+    asm volatile("" : "+v"(m));
+    const int nl = wn * (BN / WGN) + j * 16 + fq * 4;
+    unsigned lo = fin[i][j].x, hi = fin[i][j].y;
+    if (epi & PP_EPI_GELU) {
+      float v[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                    __uint_as_float(hi & 0xffff0000u)};
+      gelu4<bf16_t>(v);
+      lo = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+      hi = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    }
+    if (m < p.M && prev_n0 + nl < p.N) {
+      const unsigned long long pk = (unsigned long long)lo | ((unsigned long long)hi << 32);
+      bf16_t *dst = Cb + (size_t)m * p.ldc + prev_n0 + nl;
+#ifdef PP_P13_NOSTORE
+      asm volatile("" ::"v"(dst), "v"(pk) : "memory");
+#else
+      asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pk) : "memory");
+#endif
+    }
+  };
+  auto run_slice = [&](int sl) __attribute__((always_inline)) {   // wave-uniform sl: one of NSLICE straight-line copies
+    [&]<int... SL>(std::integer_sequence<int, SL...>) {
+      ([&] {
+        if (sl == SL) {
+          half_slice(std::integral_constant<int, 2 * SL>{});
+          half_slice(std::integral_constant<int, 2 * SL + 1>{});
+        }
+      }(), ...);
+    }(std::make_integer_sequence<int, NSLICE>{});
+  };
+
+  // ---- the stream: fill two K-tiles, then one identical iteration per K-tile, tile after tile
+#ifdef PP_GEMM_STAMPS
+  unsigned long long c_wait = 0, c_bar = 0, c_stage = 0, c_comp = 0, c_end = 0;
+#endif
+  PP_STAMP(t_begin);
+  stage_all(0);
+  stage_all(1);
+  int buf = 0, c_slot = 0;
+  for (int t_vb = next_valid((int)blockIdx.x); t_vb >= 0; t_vb = next_valid(t_vb + (int)gridDim.x)) {
+    int tm, tn;
+    decode(t_vb, tm, tn);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {
+      PP_STAMP(ta);
+      wait_vmcnt<PIECES>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PP_STAMP(tb);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(tc);
+#ifndef PP_P13_NOSLICE
+      if (have_prev && kt < NSLICE) run_slice(kt);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(td);
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage_begin(nb);
+      compute(buf);
+      PP_STAMP(te);
+      stage_end();
+      PP_STAMP(tf);
+      PP_ACC(c_wait, ta, tb);
+      PP_ACC(c_bar, tb, tc);
+      PP_ACC(c_stage, tc, td);
+      PP_ACC(c_comp, td, te);
+      PP_ACC(c_end, te, tf);
+      if (++buf == STAGES) buf = 0;
+    }
+    if (have_prev)
+      for (int sl = min(nkt, NSLICE); sl < NSLICE; ++sl) run_slice(sl);
+    // tile boundary: accumulators + bias -> packed bf16 (ReLU commutes with the rounding and is applied here)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (epi & PP_EPI_BIAS)
+        b4 = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + c_slot * BIAS_SLOT +
+                                               (wn * (BN / WGN) + j * 16 + fq * 4) * 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
+        if (epi & PP_EPI_RELU) {
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+        }
+        fin[i][j] = u32x2{(unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16),
+                          (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16)};
+      }
+    }
+    prev_m0 = tm * BM; prev_n0 = tn * BN; have_prev = true;
+    c_slot = c_slot == 2 ? 0 : c_slot + 1;
+  }
+  PP_STAMP(t_loop);
+  wait_vmcnt<0>();      // the dummy pieces of the last two iterations must not outlive the workgroup's LDS allocation
+  // the last tile of this workgroup: nothing left to hide its epilogue under
+  for (int sl = 0; sl < NSLICE; ++sl) run_slice(sl);
+#ifdef PP_GEMM_STAMPS
+  if ((p.epilogue & (1 << 30)) && lane == 0) {
+    PP_STAMP(t_end);
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
+                            ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = c_end; o[1] = c_wait; o[2] = c_bar; o[3] = c_stage; o[4] = c_comp;
+    o[5] = t_end - t_loop; o[6] = t_end - t_begin; o[7] = t_begin;
+  }
+#endif
+}
+
 }  // namespace pp
 
 #ifndef PP_CFG5_VS_CFG3
@@ -1265,7 +1572,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
   // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 12, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 13, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -1288,7 +1595,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12 || cfg == 13) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   dim3 grid;
@@ -1314,6 +1621,34 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_REQUIRE(a->stats_parts == p.tiles_n, "pp_gemm: stats_parts=%d but this launch has %d column tiles",
                a->stats_parts, p.tiles_n);
   hipStream_t s = (hipStream_t)stream;
+  if (cfg == 13) {
+    // persistent 192x192 form (gemm_persist_kernel): plain bf16 -> bf16 layers only
+    PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && p.lds_epilogue && batch == 1 &&
+                   !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | (1 << 30))),
+               "pp_gemm: tile 13 (persistent) serves plain bf16 -> bf16 GEMMs with bias / GELU / ReLU epilogues only");
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0, n = 0;
+      PP_CHECK_HIP(hipGetDevice(&dev));
+      PP_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+      ncu = n > 0 ? n : 256;
+    }
+    const int vblocks = (int)grid.x;
+    int wgs = std::min(vblocks, ncu);
+    if (wgs >= 8) wgs &= ~7;                      // a multiple of 8 keeps every workgroup's tiles on its XCD
+    constexpr int lds = 3 * (192 + 192) * ROW_BYTES + 3 * 192 * 4;
+    static thread_local int attr_dev = -1;
+    int dev = 0;
+    PP_CHECK_HIP(hipGetDevice(&dev));
+    if (attr_dev != dev) {
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_persist_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      attr_dev = dev;
+    }
+    hipLaunchKernelGGL(gemm_persist_kernel, dim3(wgs), dim3(512), lds, s, p, vblocks);
+    PP_CHECK_LAUNCH("gemm_persist_kernel");
+    return 0;
+  }
 #define PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_)                         \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \

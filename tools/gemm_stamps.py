@@ -35,7 +35,7 @@ a = _lib.GemmArgs()
 a.A, a.W, a.C, a.bias = A.data_ptr(), W.data_ptr(), out.data_ptr(), b.data_ptr()
 a.rowbias = stamps.data_ptr()
 a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
-a.batch, a.dtype, a.epilogue, a.tile = 1, 1, (1 | 8 | 16 if RESID else 1) | (1 << 30), tile
+a.batch, a.dtype, a.epilogue, a.tile = 1, 1, (1 | 8 | 16 if RESID else 1) | (1 << 30) | (2 if 'gelu' in sys.argv else 0), tile
 if RESID:
     a.residual = out.data_ptr()
 for _ in range(3):
@@ -44,6 +44,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 s_all = stamps.cpu().numpy().reshape(-1, 8, 8)          # [workgroup, wave, field]
 names = ["prologue", "vmcnt wait", "barrier", "stage issue", "compute", "epilogue", "total"]
+if tile == 13:   # persistent: per-workgroup totals over all its tiles
+    names = ["stream advance", "vmcnt wait", "barrier", "deferred slice", "compute", "last epilogue", "total"]
 if tile == 10:   # ping-pong: fields are frag-read issue / wait+barrier / DMA issue / MFMA, per wave role
     names = ["prologue", "frag reads", "wait+barrier", "DMA issue", "MFMA", "epilogue", "total"]
 print(f"M={M} N={N} K={K} tile={tile}: K-tiles = {K // 64}")
