@@ -186,6 +186,15 @@ int pp_final_logits(const void *x, const void *w, const float *bias, float *out,
  * Martins & Astudillo 2016 -- parity unpinned) + head.py:529-531 (x * normalize, clamp).  One workgroup per row. */
 int pp_sparsemax_rows(float *x, long long rows, int n, float scale, void *stream);
 
+/* ArgMaxProbMap.decode (codec.py:515-543): raw arg-max of every heatmap (heatmap.py:13-52 get_heatmap_maximum)
+ * refined by DARK-UDP (codec.py:315-375: Gaussian blur codec.py:284-313, clip, log, 3x3 Hessian step), rescaled to
+ * input pixels.  heatmaps [B,K,H,W] f32; taps_host = the ksize float32 coefficients of cv2.getGaussianKernel(ksize, 0)
+ * (host memory, copied into the launch); outputs kpts [B,K,2] f64, scores [B,K] f32 (raw maxima), locs [B,K,2] f32
+ * (integer arg-max, (-1,-1) where the maximum is <= 0).  cv2 is not importable here: parity unpinned. */
+size_t pp_dark_decode_lds_bytes(int H, int W, int ksize);
+int pp_dark_decode_f32(const float *heatmaps, int B, int K, int H, int W, const float *taps_host, int ksize,
+                       double in_w, double in_h, double *out_kpts, float *out_scores, float *out_locs, void *stream);
+
 /* Aux tail: 1x1 conv C->K on pooled 1x1 features + Sigmoid/ReLU (head.py:277-286,:391-400).
  * x [4 branches][B, C] -> out [4][B,K] f32 (branches 0..2 sigmoid, 3 relu). */
 int pp_aux_tail(const void *x, const void *w, const float *bias, float *out, int B, int C,

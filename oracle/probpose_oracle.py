@@ -401,3 +401,90 @@ def synthetic_keypoints(K: int, input_size, seed: int):
     vis[0, 0] = vis[0, 1] = 1.0
     return kp, vis
 
+
+
+# --------------------------------------------------------------------------
+# f2: ArgMaxProbMap.decode = raw arg-max + DARK-UDP            probpose/codec.py:284-375,515-543
+# (cv2.GaussianBlur is third-party and not importable here: PARITY UNPINNED; restated from OpenCV's published
+#  getGaussianKernel / separable float32 filtering.  The zero padding of codec.py:305-306 is as wide as the kernel
+#  radius, so cv2's own border mode (BORDER_REFLECT_101) never reaches the cropped result.)
+# --------------------------------------------------------------------------
+def get_heatmap_maximum(heatmaps: np.ndarray):
+    """heatmap.py:13-52 (pinned by tests/golden/metrics.npz, minted from the imported reference)."""
+    if heatmaps.ndim == 3:
+        K, H, W = heatmaps.shape
+        B = None
+        flat = heatmaps.reshape(K, -1)
+    else:
+        B, K, H, W = heatmaps.shape
+        flat = heatmaps.reshape(B * K, -1)
+    y_locs, x_locs = np.unravel_index(np.argmax(flat, axis=1), shape=(H, W))
+    locs = np.stack((x_locs, y_locs), axis=-1).astype(np.float32)
+    vals = np.amax(flat, axis=1)
+    locs[vals <= 0.0] = -1
+    if B:
+        locs = locs.reshape(B, K, 2)
+        vals = vals.reshape(B, K)
+    return locs, vals
+
+
+def gaussian_kernel_f32(ksize: int) -> np.ndarray:
+    """cv2.getGaussianKernel(ksize, sigma <= 0, CV_32F) as OpenCV's source computes it."""
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    t = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)
+    return (t.astype(np.float64) * (1.0 / t.astype(np.float64).sum())).astype(np.float32)
+
+
+def gaussian_blur_zero_padded(hm: np.ndarray, ksize: int) -> np.ndarray:
+    """codec.py:300-312 for one (H, W) float32 map: zero-pad by the radius, separable float32 Gaussian, crop, rescale to
+    the original maximum.  Row pass: taps in index order; column pass: centre tap + symmetric pairs; every product and
+    sum rounded to float32 (no fused multiply-add)."""
+    k = gaussian_kernel_f32(ksize)
+    b = (ksize - 1) // 2
+    H, W = hm.shape
+    origin_max = np.max(hm)
+    P = np.zeros((H + 2 * b, W + 2 * b), dtype=np.float32)
+    P[b:b + H, b:b + W] = hm
+    R = np.zeros((H + 2 * b, W), dtype=np.float32)
+    acc = k[0] * P[b:b + H, 0:W]
+    for t in range(1, ksize):
+        acc = acc + k[t] * P[b:b + H, t:t + W]
+    R[b:b + H] = acc
+    out = k[b] * R[b:b + H]
+    for t in range(1, b + 1):
+        out = out + k[b + t] * (R[b + t:b + t + H] + R[b - t:b - t + H])
+    out = out.astype(np.float32)
+    out *= origin_max / (np.max(out) + 1e-12)
+    return out
+
+
+def dark_udp_decode(heatmaps: np.ndarray, blur_kernel_size: int, input_size, heatmap_size):
+    """ArgMaxProbMap.decode (codec.py:515-543) for one crop's (K, H, W) float32 maps -> (kpts (1,K,2) f64,
+    scores (1,K) f32).  A map whose maximum is <= 0 keeps the location (-1, -1) un-refined (the reference reads a
+    neighbouring map through negative indices there: defined behaviour instead of that out-of-bounds read)."""
+    hm = heatmaps.astype(np.float32).copy()
+    W, H = heatmap_size
+    K = hm.shape[0]
+    locs, scores = get_heatmap_maximum(hm)
+    kp = locs.copy()
+    for k in range(K):
+        if not scores[k] > 0:
+            continue
+        L = gaussian_blur_zero_padded(hm[k], blur_kernel_size)
+        np.clip(L, 1e-3, 50., L)
+        np.log(L, L)
+        Lp = np.pad(L, ((1, 1), (1, 1)), mode="edge")
+        x, y = int(locs[k, 0]) + 1, int(locs[k, 1]) + 1
+        i_, ix1, iy1 = Lp[y, x], Lp[y, x + 1], Lp[y + 1, x]
+        ix1y1, ix1_y1_, ix1_, iy1_ = Lp[y + 1, x + 1], Lp[y - 1, x - 1], Lp[y, x - 1], Lp[y - 1, x]
+        dx = np.float32(0.5) * (ix1 - ix1_)
+        dy = np.float32(0.5) * (iy1 - iy1_)
+        dxx = ix1 - 2 * i_ + ix1_
+        dyy = iy1 - 2 * i_ + iy1_
+        dxy = np.float32(0.5) * (ix1y1 - ix1 - iy1 + i_ + i_ - ix1_ - iy1_ + ix1_y1_)
+        hess = np.array([[dxx, dxy], [dxy, dyy]], dtype=np.float32)
+        hinv = np.linalg.pinv(hess + np.finfo(np.float32).eps * np.eye(2))
+        kp[k] -= (hinv @ np.array([dx, dy], dtype=np.float32).reshape(2, 1)).squeeze()
+    kpts = kp[None] / [W - 1, H - 1] * input_size
+    return kpts, scores[None]

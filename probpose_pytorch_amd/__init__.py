@@ -9,10 +9,10 @@ is no CPU fallback: without the built extension or without a gfx950 device
 the hot-path calls raise.
 """
 from .util import to_numpy  # noqa: F401
-from .codec import Codec, ProbMap  # noqa: F401
+from .codec import ArgMaxProbMap, Codec, ProbMap  # noqa: F401
 from .heatmap import get_heatmap_expected_value  # noqa: F401
 
-__all__ = ["to_numpy", "Codec", "ProbMap", "get_heatmap_expected_value"]
+__all__ = ["to_numpy", "Codec", "ProbMap", "ArgMaxProbMap", "get_heatmap_expected_value"]
 
 
 def __getattr__(name):  # lazy: the nn.Module side pulls in the engine

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "pp_final_heatmap": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "pp_final_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "pp_sparsemax_rows": (C.c_int, [_vp, C.c_longlong, _i, _f, _vp]),
+    "pp_dark_decode_lds_bytes": (C.c_size_t, [_i, _i, _i]),
+    "pp_dark_decode_f32": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp, _vp, _vp]),
     "pp_aux_tail": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_tokens_to_nchw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_nchw_to_tokens": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -95,6 +95,15 @@ class VisionTransformer(nn.Module):
         """dtype of forward_tokens' result (fp8 mode keeps tokens, attention and the head in bf16)."""
         return torch.bfloat16 if self.compute_dtype == torch.float8_e4m3fn else self.compute_dtype
 
+    def calibrate_fp8(self, batches, margin: float = None):
+        """fp8 compute mode: fix the static activation scales from representative batches (see engine.VitPlan.calibrate)."""
+        batches = list(batches)
+        if not batches:
+            raise ValueError("calibrate_fp8 needs at least one batch")
+        _lib.require_device(batches[0])
+        self._plan(batches[0].device).calibrate(batches, margin)
+        return self
+
     def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
         """(B,3,H,W) -> device-resident tokens [B*N, C] in the compute dtype (HIP only)."""
         _lib.require_device(x)
@@ -105,7 +114,9 @@ class VisionTransformer(nn.Module):
         """(B,3,H,W) -> (B,N,C) float32, as timm's ``forward_features``."""
         B = x.shape[0]
         t = self.forward_tokens(x)
-        return t.float().reshape(B, self.patch_embed.num_patches, self.embed_dim)
+        # forward_tokens hands out the plan's cached workspace; timm returns a fresh tensor, so copy out (in fp32 mode
+        # .float() alone would alias the scratch buffer and the next forward would overwrite this result)
+        return t.to(torch.float32, copy=True).reshape(B, self.patch_embed.num_patches, self.embed_dim)
 
     def forward(self, x):
         return self.forward_features(x)

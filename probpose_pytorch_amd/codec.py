@@ -108,6 +108,66 @@ class ProbMap:
                     identification_similarity=id_similarity)
 
 
+def gaussian_blur_taps(ksize: int) -> np.ndarray:
+    """The float32 coefficients cv2.GaussianBlur(img_f32, (k, k), 0) filters with (reference codec.py:310):
+    sigma = 0.3 * ((k - 1) * 0.5 - 1) + 0.8, t_i = float32(exp(-0.5 x_i^2 / sigma^2)), normalised by the float64 sum
+    of the float32 values (OpenCV getGaussianKernel, CV_32F).  Restated from OpenCV's published source; cv2 itself is
+    not importable here (parity unpinned)."""
+    if ksize % 2 != 1 or ksize < 1:
+        raise AssertionError("kernel size must be odd")
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    t = np.exp(-0.5 / (sigma * sigma) * x * x).astype(np.float32)
+    return (t.astype(np.float64) * (1.0 / t.astype(np.float64).sum())).astype(np.float32)
+
+
+class ArgMaxProbMap(ProbMap):
+    """Reference codec.py:377-543: same targets as ProbMap (encode), decoding by raw arg-max + DARK-UDP refinement
+    (codec.py:515-543) -- the decoder the reference's loss calls (train.py:47-48).  ``decode`` runs one fused HIP
+    launch over the whole batch (csrc/pp_dark.hip)."""
+
+    def __init__(self, input_size, heatmap_size, sigmas=None, sigma: float = -1, radius_factor: float = 0.0546875,
+                 blur_kernel_size: int = 11, increase_sigma_with_padding=False) -> None:
+        super().__init__(input_size, heatmap_size, sigmas, sigma=sigma, radius_factor=radius_factor,
+                         blur_kernel_size=blur_kernel_size, increase_sigma_with_padding=increase_sigma_with_padding)
+
+    def decode_device(self, heatmaps: torch.Tensor, aux=None) -> dict:
+        """(B,K,H,W) f32 device heatmaps -> dict(kpts (B,K,2) f64, scores (B,K) f32, locs (B,K,2) f32) on the device."""
+        _lib.require_device(heatmaps)
+        hm = heatmaps.detach()
+        if hm.dtype != torch.float32 or not hm.is_contiguous():
+            hm = hm.float().contiguous()
+        B, K, H, W = hm.shape
+        taps = np.ascontiguousarray(gaussian_blur_taps(int(self.blur_kernel_size)))
+        kpts = torch.empty((B, K, 2), dtype=torch.float64, device=hm.device)
+        scores = torch.empty((B, K), dtype=torch.float32, device=hm.device)
+        locs = torch.empty((B, K, 2), dtype=torch.float32, device=hm.device)
+        with torch.cuda.device(hm.device):
+            rc = _lib.lib().pp_dark_decode_f32(_lib.ptr(hm), B, K, H, W, taps.ctypes.data, taps.shape[0],
+                                               float(self.input_size[0]), float(self.input_size[1]), _lib.ptr(kpts),
+                                               _lib.ptr(scores), _lib.ptr(locs), _lib.stream_ptr())
+        _lib.check(rc, "pp_dark_decode_f32")
+        out = dict(kpts=kpts, scores=scores, locs=locs)
+        if aux is not None:       # Codec.decode's pass-through of the four scalar heads (codec.py:254-261)
+            a = [t.reshape(B, K).float() for t in aux]
+            out["aux"] = torch.stack(a[:3])
+            out["err"] = a[3].double() / float(np.sqrt(H * H + W * W))
+        return out
+
+    def decode(self, encoded):
+        """(K,H,W) [or (B,K,H,W)] heatmaps -> keypoints (1,K,2) f64 [or (B,K,2)], scores (1,K) f32 [or (B,K)]."""
+        _lib.require_device()
+        t = torch.from_numpy(np.ascontiguousarray(encoded)) if isinstance(encoded, np.ndarray) else encoded
+        if t.ndim == 3:
+            t = t[None]
+        if t.ndim != 4:
+            raise AssertionError(f"Invalid shape {tuple(t.shape)}")
+        if not t.is_cuda:
+            t = t.cuda(non_blocking=True)
+        out = self.decode_device(t)
+        return out["kpts"].cpu().numpy(), out["scores"].cpu().numpy()
+
+
 class Codec:
     """Reference codec.py:242-267."""
 

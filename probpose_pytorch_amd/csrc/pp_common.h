@@ -66,4 +66,17 @@ __device__ __forceinline__ float wave_max(float v) {
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute (dynamic-LDS limit) is per device: the "already raised" caches are bitmasks over the device
+// ordinal of the calling thread's current device, not a single flag (a second GPU in the same thread would otherwise
+// launch with the 64 KB default limit and fail).
+inline bool attr_needed(unsigned long long &mask, int &dev_out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  dev_out = dev;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 }  // namespace pp

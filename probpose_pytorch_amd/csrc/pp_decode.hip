@@ -474,12 +474,11 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   const int maps = B * K;
   if (fits_lds(H, W)) {
     const size_t lds = lds_bytes(H, W);
-    static thread_local size_t attr_set = 0;
-    if (lds > 64 * 1024 && lds > attr_set) {
+    static thread_local unsigned long long attr_mask = 0;
+    int dev_ = 0;
+    if (lds > 64 * 1024 && attr_needed(attr_mask, dev_))
       PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_lds_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-      attr_set = LDS_LIMIT;
-    }
     hipLaunchKernelGGL(decode_lds_kernel, dim3(maps), dim3(DEC_THREADS), lds, s, heatmaps, prob, vis,
                        oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w, in_h, o, out_conv);
     PP_CHECK_LAUNCH("decode_lds_kernel");

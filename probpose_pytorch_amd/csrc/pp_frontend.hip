@@ -434,12 +434,11 @@ extern "C" int pp_frontend_crop_resize(const unsigned char *image, int img_w, in
   PP_REQUIRE(image && plan_dev && out, "pp_frontend_crop_resize: null pointer");
   PP_REQUIRE(lds_bytes > 0 && (size_t)lds_bytes <= FE_LDS_MAX, "pp_frontend_crop_resize: bad LDS size %lld", lds_bytes);
   if (lds_bytes > 64 * 1024) {
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
+    static thread_local unsigned long long attr_mask = 0;
+    int dev_ = 0;
+    if (attr_needed(attr_mask, dev_))
       PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(crop_resize_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)FE_LDS_MAX));
-      attr_set = true;
-    }
   }
   hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)n_blocks), dim3(FE_THREADS), (size_t)lds_bytes,
                      (hipStream_t)stream, image, img_w, img_h, img_stride, static_cast<const int *>(plan_dev), n_boxes,

@@ -1637,14 +1637,11 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     int wgs = std::min(vblocks, ncu);
     if (wgs >= 8) wgs &= ~7;                      // a multiple of 8 keeps every workgroup's tiles on its XCD
     constexpr int lds = 3 * (192 + 192) * ROW_BYTES + 3 * 192 * 4;
-    static thread_local int attr_dev = -1;
-    int dev = 0;
-    PP_CHECK_HIP(hipGetDevice(&dev));
-    if (attr_dev != dev) {
+    static thread_local unsigned long long attr_mask = 0;
+    int dev_ = 0;
+    if (attr_needed(attr_mask, dev_))
       PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_persist_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      attr_dev = dev;
-    }
     hipLaunchKernelGGL(gemm_persist_kernel, dim3(wgs), dim3(512), lds, s, p, vblocks);
     PP_CHECK_LAUNCH("gemm_persist_kernel");
     return 0;
@@ -1652,13 +1649,12 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
 #define PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_)                         \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
-    static thread_local bool attr = false;                                                            \
-    if (!attr) {                                                                                      \
+    static thread_local unsigned long long attr_mask = 0;                                             \
+    int dev_ = 0;                                                                                     \
+    if (attr_needed(attr_mask, dev_))                                                                 \
       PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
           reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
-      attr = true;                                                                                    \
-    }                                                                                                 \
     hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_>), grid,     \
                        dim3(64 * (WGM_ * WGN_ + NWP_)), lds, s, p);                                   \
   } while (0)

@@ -163,14 +163,11 @@ extern "C" int pp_sparsemax_rows(float *x, long long rows, int n, float scale, v
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)n * 4;
   if (lds <= 150 * 1024) {
-    static thread_local int attr_dev = -1;
-    int dev = 0;
-    PP_CHECK_HIP(hipGetDevice(&dev));
-    if (attr_dev != dev) {
+    static thread_local unsigned long long attr_mask = 0;
+    int dev_ = 0;
+    if (attr_needed(attr_mask, dev_))
       PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sparsemax_rows_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_dev = dev;
-    }
     hipLaunchKernelGGL(sparsemax_rows_kernel<true>, dim3((unsigned)rows), dim3(SM_THREADS), lds, s, x, n, scale);
   } else {
     hipLaunchKernelGGL(sparsemax_rows_kernel<false>, dim3((unsigned)rows), dim3(SM_THREADS), 0, s, x, n, scale);

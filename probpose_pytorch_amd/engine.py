@@ -63,18 +63,25 @@ def _dev(t: torch.Tensor, device, dtype=None):
 
 
 class _Workspace:
-    """Named scratch tensors, allocated once per batch size (stable addresses for graph capture)."""
+    """Named scratch tensors.  Every buffer is row-major [rows, ...]: one allocation per name serves every batch
+    size up to the largest seen (smaller batches get the leading rows: contiguous views at a stable address, so
+    captured graphs stay valid).  A larger batch allocates a new buffer; the old one is kept alive (a graph captured
+    at the old size still points into it) but is no longer handed out."""
 
     def __init__(self):
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._retired = []
 
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
-        key = (name, tuple(shape), dtype)
+        shape = tuple(shape)
+        key = (name, shape[1:], dtype)
         t = self._bufs.get(key)
-        if t is None:
+        if t is None or t.shape[0] < shape[0]:
+            if t is not None:
+                self._retired.append(t)
             t = torch.empty(shape, dtype=dtype, device=device)
             self._bufs[key] = t
-        return t
+        return t[: shape[0]]
 
 
 # ---------------------------------------------------------------------------
@@ -138,6 +145,10 @@ class VitPlan:
         B, ch, H, W = x.shape
         if ch != 3 or (H, W) != self.img_size:
             raise AssertionError(f"Input size ({H}, {W}) doesn't match model {self.img_size}")
+        with torch.cuda.device(self.device):      # kernels launch on the current stream of the plan's device
+            return self._forward_tokens(x, B)
+
+    def _forward_tokens(self, x: torch.Tensor, B: int) -> torch.Tensor:
         dev, dt, C, N = self.device, self.dtype, self.C, self.N
         M = B * N
         g = self.ws.get
@@ -207,28 +218,37 @@ class VitPlan:
         ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
 
 
-def _vit_calibrate_fp8(self, x, B, bufs, margin: float = 1.0):
-    """One bf16 pass over the batch recording amax of the three quantised activations of every block
-    (LN1 output, attention output, LN2 output, GELU output) -> static scales amax / 448, and the per-column dequantisation
-    vectors (activation scale x weight-row scale) of the three fp8 GEMMs."""
+FP8_MARGIN = 1.25      # head-room of the static activation scales over the calibration amax (e4m3 saturates at 448)
+
+
+def _vit_calibrate_fp8(self, x, B, bufs, margin: float = None):
+    """One bf16 pass over the batch recording amax of the four quantised activations of every block
+    (LN1 output, attention output, LN2 output, GELU output) -> static scales margin * amax / 448, and the per-column
+    dequantisation vectors (activation scale x weight-row scale) of the fp8 GEMMs.  Repeated calls
+    (VitPlan.calibrate over several batches) keep the running maximum."""
+    margin = FP8_MARGIN if margin is None else margin
     a0, xres, h, qkv, ao, hid, feats = bufs
     C, N = self.C, self.N
     M = B * N
     ops.patchify(x, a0, self.patch)
     ops.gemm(a0, self.pe_w, xres, M=M, N=C, Kd=a0.shape[1], lda=a0.shape[1], ldw=a0.shape[1], ldc=C,
              bias=self.pe_b, rowbias=self.pos, rowbias_period=N, epilogue=EPI_OUT_F32)
-    amax = lambda t: max(float(t.float().abs().max()), 1e-6) * margin / ops.FP8_MAX
+    def amax(t, blk, key):
+        a = max(float(t.float().abs().max()), 1e-6, blk.get("amax_" + key, 0.0))
+        blk["amax_" + key] = a
+        return a * margin / ops.FP8_MAX
+
     for b in self.blocks:
         ops.layernorm(xres, b["n1w"], b["n1b"], b["eps1"], h)
-        b["s_h1"] = amax(h)
+        b["s_h1"] = amax(h, b, "h1")
         ops.linear(h, b["qkv_w"], b["qkv_b"], out=qkv)
         ops.attention(qkv, ao, B, N, self.heads, self.hd)
-        b["s_ao"] = amax(ao)
+        b["s_ao"] = amax(ao, b, "ao")
         ops.linear(ao, b["proj_w"], b["proj_b"], out=xres, residual=xres)
         ops.layernorm(xres, b["n2w"], b["n2b"], b["eps2"], h)
-        b["s_h2"] = amax(h)
+        b["s_h2"] = amax(h, b, "h2")
         ops.linear(h, b["fc1_w"], b["fc1_b"], out=hid, epilogue=EPI_GELU)
-        b["s_hid"] = amax(hid)
+        b["s_hid"] = amax(hid, b, "hid")
         ops.linear(hid, b["fc2_w"], b["fc2_b"], out=xres, residual=xres)
         b["qkv_cs"] = (b["qkv_sw"] * b["s_h1"]).contiguous()
         b["proj_cs"] = (b["proj_sw"] * b["s_ao"]).contiguous()
@@ -290,6 +310,30 @@ def _vit_forward_tokens_fused(self, B, M, a0, xres, qkv, ao, hid, feats):
 VitPlan._forward_tokens_fused = _vit_forward_tokens_fused
 
 
+def _vit_calibrate(self, batches, margin: float = None):
+    """Explicit fp8 calibration over representative batches (iterable of (B,3,H,W) device tensors): the static
+    activation scales become margin * (max |activation| over all batches) / 448.  Without it the first forward
+    calibrates on its own batch."""
+    if not self.fp8:
+        raise RuntimeError("calibrate() applies to the fp8 compute mode")
+    for b in self.blocks:
+        for k in [k for k in b if k.startswith("amax_")]:
+            del b[k]
+    with torch.cuda.device(self.device), torch.no_grad():
+        for x in batches:
+            x = x.detach().contiguous().float()
+            B = x.shape[0]
+            M = B * self.N
+            g = self.ws.get
+            bufs = (g("a0", (M, 3 * self.patch ** 2), self.dtype, self.device), g("xres", (M, self.C), torch.float32, self.device),
+                    g("h", (M, self.C), self.dtype, self.device), g("qkv", (M, 3 * self.C), self.dtype, self.device),
+                    g("ao", (M, self.C), self.dtype, self.device), g("hid", (M, self.hidden), self.dtype, self.device),
+                    g("feats", (M, self.C), self.dtype, self.device))
+            self._calibrate_fp8(x, B, bufs, margin)
+    return self
+
+
+VitPlan.calibrate = _vit_calibrate
 VitPlan._calibrate_fp8 = _vit_calibrate_fp8
 VitPlan._run_chain_fp8 = _vit_run_chain_fp8
 
@@ -391,7 +435,10 @@ class HeadPlan:
         key = (B, h, w)
         t = self._tables.get(key)
         if t is not None:
+            self._tables[key] = self._tables.pop(key)          # most recently used last
             return t
+        while len(self._tables) >= 8:                          # bounded: batch sizes vary per frame in inference
+            self._tables.pop(next(iter(self._tables)))
         dev = self.device
         t = dict(deconv=[], conv=[], aux=[])
         hh, ww = h, w
@@ -421,6 +468,10 @@ class HeadPlan:
     def forward(self, feats: torch.Tensor, B: int, h: int, w: int):
         """feats: channels-last rows [B*h*w, C] in the compute dtype.
         Returns (heatmaps (B,K,Hh,Wh) f32, prob, vis, oks, err (B,K,1,1) f32)."""
+        with torch.cuda.device(self.device):      # kernels launch on the current stream of the plan's device
+            return self._forward(feats, B, h, w)
+
+    def _forward(self, feats: torch.Tensor, B: int, h: int, w: int):
         dev, dt, C, K = self.device, self.dtype, self.C, self.K
         tb = self._tables_for(B, h, w)
         g = self.ws.get

@@ -27,6 +27,13 @@ class ProbPoseModel(nn.Module):
         self.head.set_compute_dtype(torch.bfloat16 if dtype == torch.float8_e4m3fn else dtype)
         return self
 
+    def calibrate_fp8(self, batches, margin: float = None):
+        """fp8 mode only: static activation scales = margin (default 1.25) x the maximum |activation| over the given
+        batches / 448.  Call after set_compute_dtype(torch.float8_e4m3fn); otherwise the first forward calibrates on
+        its own batch."""
+        self.backbone.model.calibrate_fp8(batches, margin)
+        return self
+
     def forward(self, x: Tensor):
         if isinstance(self.backbone, ScratchViTBackbone) and isinstance(self.head, ProbMapHead) \
                 and self.backbone.model.token_dtype == self.head.compute_dtype:

@@ -17,6 +17,21 @@ import torch.distributed as dist
 
 FIELDS = ("x", "y", "score", "prob", "vis", "oks", "err")
 
+# receive / padding buffers of the all-gather, keyed by (shape, dtype, device): allocated once, reused every step
+# (no allocation inside the step; the addresses stay stable for graph capture around the collective)
+_BUFFERS: Dict[tuple, torch.Tensor] = {}
+
+
+def _buffer(tag: str, shape, dtype, device) -> torch.Tensor:
+    key = (tag, tuple(shape), dtype, str(device))
+    t = _BUFFERS.get(key)
+    if t is None:
+        if len(_BUFFERS) >= 16:
+            _BUFFERS.pop(next(iter(_BUFFERS)))
+        t = torch.zeros(shape, dtype=dtype, device=device)
+        _BUFFERS[key] = t
+    return t
+
 
 def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous [lo, hi) of rank's crops; the first total % world ranks get one extra."""
@@ -64,14 +79,16 @@ def all_gather_decoded(packed: torch.Tensor, group: Optional[dist.ProcessGroup] 
     Bmax = max(sizes) if sizes is not None else packed.shape[0]
     send = packed
     if packed.shape[0] != Bmax:
-        send = torch.zeros((Bmax,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+        send = _buffer("send", (Bmax,) + tuple(packed.shape[1:]), packed.dtype, packed.device)
         send[: packed.shape[0]] = packed
+        send[packed.shape[0]:] = 0
     send = send.contiguous()
     if dist.get_backend(group) == "nccl":
-        recv = torch.empty((world * Bmax,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        recv = _buffer("recv", (world * Bmax,) + tuple(send.shape[1:]), send.dtype, send.device)
         dist.all_gather_into_tensor(recv, send, group=group)
         if sizes is None:
             return recv                      # even shards: the gathered buffer already is [world * B, K, 7]
+                                             # (reused by the next call: consume or copy it before gathering again)
         parts = list(recv.split(Bmax))
     else:
         # gloo (CPU tests, single-GPU rehearsals of the multi-rank path): the collective runs on host copies

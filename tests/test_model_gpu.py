@@ -37,6 +37,38 @@ def _build(pkg, img, C, depth, heads, K, pools, deconv=(256, 256), seed=0):
     return m.cuda().eval(), sd
 
 
+# ---- observed end-to-end agreement, recorded and asserted against the committed observation --------------------
+# The share of decoded keypoints that agree with the CPU path to 1e-4 px (the rest are verified near-ties of the
+# random-weight heatmaps, see _assert_keypoints_match_up_to_near_ties) is written to gpurun_out/ on the GPU box and,
+# copied to profiles/r02_parity.json, becomes the threshold of later runs: observed - 0.05 (0.7 for a case that
+# has no committed observation yet).
+_PARITY_COMMITTED = os.path.join(os.path.dirname(GOLDEN), "..", "profiles", "r02_parity.json")
+_PARITY_OBSERVED = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "r02_parity_observed.json")
+
+
+def _check_and_record_fraction(name: str, frac: float, extra=None):
+    import json
+    committed = {}
+    if os.path.exists(_PARITY_COMMITTED):
+        with open(_PARITY_COMMITTED) as f:
+            committed = json.load(f).get("near_tie_free_fraction", {})
+    floor = committed[name] - 0.05 if name in committed else 0.7
+    try:
+        os.makedirs(os.path.dirname(_PARITY_OBSERVED), exist_ok=True)
+        obs = {}
+        if os.path.exists(_PARITY_OBSERVED):
+            with open(_PARITY_OBSERVED) as f:
+                obs = json.load(f)
+        obs.setdefault("near_tie_free_fraction", {})[name] = round(float(frac), 4)
+        if extra:
+            obs.setdefault("detail", {})[name] = extra
+        with open(_PARITY_OBSERVED, "w") as f:
+            json.dump(obs, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert frac >= floor, f"{name}: {frac:.4f} of keypoints within 1e-4 px, committed floor {floor:.4f}"
+
+
 def _assert_keypoints_match_up_to_near_ties(pkg, gpu_heat, ref_heat, gpu_kpts, ref_kpts, sigmas, tol=1e-4):
     """Heatmaps agree to `tol`, so the convolved maps do too (the OKS kernels are normalised): a GPU
     peak may differ from the CPU peak only where the reference map holds a near-tie, i.e. the GPU
@@ -78,14 +110,18 @@ def test_head_fp32_matches_reference_golden(pkg):
     frac = _assert_keypoints_match_up_to_near_ties(pkg, out[0].cpu().numpy(), g["heatmaps"], got[0][0], g["kpts"],
                                                    orc.COCO17_SIGMAS)
     print(f"\nhead golden: {frac:.2%} of keypoints within 1e-4 px of the reference, the rest are near-ties")
-    assert frac >= 0.7
+    _check_and_record_fraction("head_golden_c384", frac)
 
 
 @pytest.mark.parametrize("cfg", [
     dict(img=(64, 48), C=128, depth=2, heads=2, K=17, pools=[(4, 3)], deconv=(64, 64), B=3),
     dict(img=(256, 192), C=384, depth=12, heads=12, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256), B=1),
     dict(img=(256, 192), C=768, depth=12, heads=12, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256), B=2),
-], ids=["tiny", "S1-vit-s-256x192", "vit-b-256x192"])
+    # BASELINE.json configs 3 / 5 dimensions (ViT-L: C 1024, depth 24, 16 heads) and config 4 (ViT-H 384x288, K = 133,
+    # N = 432 tokens -> streaming attention with head_dim 80, 96x72 heatmaps, pools (4,3),(2,2),(3,3))
+    dict(img=(256, 192), C=1024, depth=24, heads=16, K=17, pools=[(4, 3), (2, 2), (2, 2)], deconv=(256, 256), B=2),
+    dict(img=(384, 288), C=1280, depth=32, heads=16, K=133, pools=[(4, 3), (2, 2), (3, 3)], deconv=(256, 256), B=1),
+], ids=["tiny", "S1-vit-s-256x192", "vit-b-256x192", "vit-l-256x192", "vit-h-384x288-k133"])
 def test_model_fp32_matches_cpu_oracle(pkg, cfg):
     m, sd = _build(pkg, cfg["img"], cfg["C"], cfg["depth"], cfg["heads"], cfg["K"], cfg["pools"], cfg["deconv"])
     x = pkg["syn"].synthetic_crops(cfg["B"], *cfg["img"], seed=1234)
@@ -101,16 +137,21 @@ def test_model_fp32_matches_cpu_oracle(pkg, cfg):
         assert gt.shape == wt.shape, name
         np.testing.assert_allclose(gt.cpu().numpy(), wt.numpy(), rtol=0, atol=1e-4, err_msg=name)
     H, W = cfg["img"]
-    codec = pkg["p"].Codec(pkg["p"].ProbMap((W, H), (W // 4, H // 4), orc.COCO17_SIGMAS))
+    import bench
+    sig = bench.sigmas_for(cfg["K"])
+    codec = pkg["p"].Codec(pkg["p"].ProbMap((W, H), (W // 4, H // 4), sig))
     dec = codec.decode(got)
-    ref = orc.codec_decode([w.numpy() for w in want], (W, H), (W // 4, H // 4), orc.COCO17_SIGMAS)
+    ref = orc.codec_decode([w.numpy() for w in want], (W, H), (W // 4, H // 4), sig)
     for a, b in zip(dec[1:4], ref[1:4]):
         np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
     np.testing.assert_allclose(dec[4], ref[4], rtol=0, atol=1e-4)
-    frac = _assert_keypoints_match_up_to_near_ties(pkg, got[0].cpu().numpy(), want[0].numpy(), dec[0][0], ref[0][0],
-                                                   orc.COCO17_SIGMAS)
+    frac = _assert_keypoints_match_up_to_near_ties(pkg, got[0].cpu().numpy(), want[0].numpy(), dec[0][0], ref[0][0], sig)
     print(f"\n[{cfg['C']}] keypoints within 1e-4 px of the CPU path: {frac:.2%} (the rest are verified near-ties)")
-    assert frac >= 0.7
+    d = np.abs(dec[0][0] - ref[0][0]).max(-1)
+    _check_and_record_fraction(f"fp32_C{cfg['C']}_{H}x{W}_K{cfg['K']}", frac,
+                               dict(heatmap_abs_max=float((got[0].cpu() - want[0]).abs().max()),
+                                    kpt_px_median=float(np.median(d)), kpt_px_max=float(d.max()),
+                                    keypoints=int(d.size)))
 
 
 def test_model_bf16_deviation_is_bounded_and_reported(pkg):
@@ -200,6 +241,67 @@ def test_full_size_forward_properties_vit_b_bs64(pkg):
     assert dec[0][0].shape == (2, 17, 2) and np.isfinite(dec[0][0]).all()
 
 
+def _full_size_properties(pkg, name, dtype, B, sub=(3, 5)):
+    """Size-independent properties of a full-size forward + decode (the CPU oracle cannot run these batches):
+    determinism, independence of batch position / batch size, well-formed decode."""
+    import bench
+    cfg = dict(bench.CONFIGS[name])
+    model, codec, sd = bench.build(cfg, dtype, torch.device("cuda", 0))
+    H, W = cfg["img"]
+    x = pkg["syn"].synthetic_crops(B, H, W, seed=78).cuda()
+    with torch.no_grad():
+        full = [o.clone() for o in model(x)]
+        again = model(x)
+        for a, b in zip(full, again):
+            assert torch.equal(a, b)
+        lo, hi = sub
+        part = model(x[lo:hi].contiguous())
+        for a, b in zip(full, part):
+            assert torch.equal(a[lo:hi], b)
+        dec = codec.decode_device(full)
+    k = dec["kpts"].cpu().numpy()
+    assert k.shape == (B, cfg["K"], 2) and np.isfinite(k).all()
+    assert (k[..., 0] >= -0.5 * W / (W // 4)).all() and (k[..., 0] <= W + 2).all()
+    assert (k[..., 1] >= -0.5 * H / (H // 4)).all() and (k[..., 1] <= H + 2).all()
+    hm = full[0]
+    assert hm.shape == (B, cfg["K"], H // 4, W // 4) and float(hm.min()) >= 0 and float(hm.max()) <= 1
+    del model
+    torch.cuda.empty_cache()
+    return cfg, sd, x, full
+
+
+def test_full_size_forward_properties_vit_l_bs256_bf16(pkg):
+    """BASELINE.json configs[2]: ViT-L 256x192 K=17 bf16, batch 256 (MFMA attention tiling)."""
+    cfg, sd, x, full = _full_size_properties(pkg, "vit_l", torch.bfloat16, 256)
+    with torch.no_grad():
+        want = orc.model_forward(sd, x[:2].cpu(), patch=16, heads=cfg["heads"], pools=cfg["pools"])
+    dh = (full[0][:2].cpu() - want[0]).abs()
+    assert float(dh.mean()) < 0.03, float(dh.mean())
+
+
+def test_full_size_forward_properties_vit_h_wholebody_bs128_bf16(pkg):
+    """BASELINE.json configs[3]: ViT-H 384x288 K=133, 128 crops per GPU (x 8 GPUs = 1024 by the driver)."""
+    cfg, sd, x, full = _full_size_properties(pkg, "vit_h_wholebody", torch.bfloat16, 128)
+    with torch.no_grad():
+        want = orc.model_forward(sd, x[:1].cpu(), patch=16, heads=cfg["heads"], pools=cfg["pools"])
+    dh = (full[0][:1].cpu() - want[0]).abs()
+    assert float(dh.mean()) < 0.03, float(dh.mean())
+
+
+def test_full_size_forward_properties_vit_l_bs256_fp8(pkg):
+    """BASELINE.json configs[4]: ViT-L fp8 weights / activations, batch 256.  No fp8 reference exists: properties
+    + the deviation from the bf16 path of the same model on the same batch is bounded loosely and recorded."""
+    import bench
+    cfg, sd, x, full8 = _full_size_properties(pkg, "vit_l", torch.float8_e4m3fn, 256)
+    model, codec, _ = bench.build(cfg, torch.bfloat16, torch.device("cuda", 0))
+    with torch.no_grad():
+        ref = model(x[:16].contiguous())
+    d = (full8[0][:16].float() - ref[0].float()).abs()
+    assert float(d.mean()) < 0.05, float(d.mean())
+    _check_and_record_fraction("fp8_vit_l_heatmap_mean_abs_dev_vs_bf16_x1000", 1.0,
+                               dict(heatmap_abs_mean=float(d.mean()), heatmap_abs_max=float(d.max())))
+
+
 def test_run_inference_on_boxes_matches_crop_then_forward(pkg):
     """frame + boxes -> crops -> forward -> decode == forward of the Pillow-made crops; keypoints mapped
     back into the frame with the inverse of dataset.py:87-89."""
@@ -274,3 +376,125 @@ def test_optional_schedules_give_identical_results(pkg, monkeypatch):
     torch.cuda.synchronize()
     for a, b, c in zip(ref, dual, serial):
         assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_timm_surface_returns_fresh_tensors(pkg):
+    """timm's forward_features / forward return new tensors: two consecutive results must not alias the plan's
+    cached workspace (in fp32 mode .float() is a no-op and a view of the scratch buffer would be overwritten)."""
+    m, _ = _build(pkg, (64, 48), 128, 1, 2, 5, [(4, 3)], (64,))
+    x1 = pkg["syn"].synthetic_crops(2, 64, 48, seed=1).cuda()
+    x2 = pkg["syn"].synthetic_crops(2, 64, 48, seed=2).cuda()
+    vit = m.backbone.model
+    for dtype in (torch.float32, torch.bfloat16):
+        m.set_compute_dtype(dtype)
+        a = vit.forward_features(x1)
+        a_copy = a.clone()
+        b = vit.forward_features(x2)
+        assert a.dtype == torch.float32 and a.shape == (2, 12, 128)
+        assert torch.equal(a, a_copy) and not torch.equal(a, b)
+        assert a.data_ptr() != b.data_ptr()
+        assert torch.equal(vit(x1), a)
+    # a smaller batch after a larger one reuses the leading rows of the same workspace; results unchanged
+    m.set_compute_dtype(torch.float32)
+    big = m(torch.cat([x1, x2]))
+    small = m(x1)
+    for u, v in zip(big, small):
+        assert torch.equal(u[:2], v)
+
+
+def test_fp8_explicit_calibration_covers_a_brighter_batch(pkg):
+    """static fp8 activation scales came from the first batch with margin 1.0 and later batches with
+    larger activations saturated silently.  calibrate_fp8() fixes the scales from given batches with head-room
+    (margin 1.25); a model calibrated on both batches must track bf16 on the high-contrast batch at least as well as
+    one calibrated on the flat batch only."""
+    model, _ = _build(pkg, (256, 192), 384, 4, 12, 17, [(4, 3), (2, 2), (2, 2)])
+    flat = (pkg["syn"].synthetic_crops(4, 256, 192, seed=3) * 0.2 + 0.4).cuda()
+    g = torch.Generator().manual_seed(9)
+    bright = (torch.rand((4, 3, 256, 192), generator=g) > 0.5).float().cuda()          # saturated black / white pixels
+    with torch.no_grad():
+        model.set_compute_dtype(torch.bfloat16)
+        ref = model(bright)[0].float().clone()
+        model.set_compute_dtype(torch.float8_e4m3fn)
+        model.calibrate_fp8([flat])
+        d_flat_only = float((model(bright)[0].float() - ref).abs().mean())
+        model.calibrate_fp8([flat, bright])
+        out = model(bright)[0].float()
+        d_both = float((out - ref).abs().mean())
+        again = model(bright)[0].float()
+    assert torch.isfinite(out).all() and torch.equal(out, again)
+    assert d_both <= d_flat_only * 1.05 + 1e-4, (d_both, d_flat_only)
+    assert d_both < 0.05
+    with pytest.raises(RuntimeError):
+        model.set_compute_dtype(torch.bfloat16)
+        model.calibrate_fp8([flat])
+
+
+def test_checkpoint_interop_state_dict_roundtrip(pkg, tmp_path):
+    """a checkpoint with the reference's parameter names (timm ViT names under
+    backbone.model.*, head.* with BatchNorm running statistics and num_batches_tracked), written by torch.save outside
+    probpose_pytorch_amd.synthetic, loaded through inference.load_weights (weights_only=True) and run in fp32 / bf16 /
+    fp8: fp32 must match the CPU oracle evaluated on the same tensors to 1e-4, bf16 / fp8 stay within their bounds.
+    Also the head-only checkpoint flavour of the reference CLI (inference.py:61-70, --model_type head)."""
+    from probpose_pytorch_amd import inference
+    img, C, depth, heads, K, pools = (256, 192), 384, 3, 6, 17, [(4, 3), (2, 2), (2, 2)]
+
+    def fresh():
+        return pkg["model"].ProbPoseModel(
+            pkg["backbone"].ScratchViTBackbone(img, 16, embed_dim=C, depth=depth, num_heads=heads),
+            pkg["head"].ProbMapHead(C, K, pools, (256, 256), (4, 4), final_layer_kernel_size=1))
+
+    src = fresh()
+    g = torch.Generator().manual_seed(2026)
+    with torch.no_grad():
+        for name, prm in src.named_parameters():
+            if prm.ndim >= 2:
+                fan_in = prm[0].numel() if "deconv" not in name else prm.shape[0] * prm.shape[2] * prm.shape[3]
+                prm.copy_(torch.randn(prm.shape, generator=g) * fan_in ** -0.5)
+            elif name.endswith("weight"):                       # LayerNorm / BatchNorm gamma
+                prm.copy_(1.0 + 0.2 * torch.randn(prm.shape, generator=g))
+            else:
+                prm.copy_(0.1 * torch.randn(prm.shape, generator=g))
+        for name, buf in src.named_buffers():
+            if name.endswith("running_mean"):
+                buf.copy_(0.3 * torch.randn(buf.shape, generator=g))
+            elif name.endswith("running_var"):
+                buf.copy_(0.5 + torch.rand(buf.shape, generator=g))
+            elif name.endswith("num_batches_tracked"):
+                buf.fill_(1234)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    assert any(k.endswith("num_batches_tracked") for k in sd) and "backbone.model.blocks.0.attn.qkv.weight" in sd
+    full_path, head_path = tmp_path / "full.pth", tmp_path / "head.pth"
+    torch.save(sd, full_path)
+    torch.save({k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}, head_path)
+
+    x = pkg["syn"].synthetic_crops(3, *img, seed=8)
+    with torch.no_grad():
+        want = orc.model_forward(sd, x, patch=16, heads=heads, pools=pools)
+    m = fresh()
+    msg = inference.load_weights(m, full_path, "full")
+    assert not msg.missing_keys and not msg.unexpected_keys
+    m = m.cuda().eval()
+    with torch.no_grad():
+        got = m(x.cuda())
+        for gt, wt, name in zip(got, want, ("heatmaps", "prob", "vis", "oks", "err")):
+            np.testing.assert_allclose(gt.cpu().numpy(), wt.numpy(), rtol=0, atol=1e-4, err_msg=name)
+        m.set_compute_dtype(torch.bfloat16)
+        got16 = [t.float().cpu() for t in m(x.cuda())]
+        m.set_compute_dtype(torch.float8_e4m3fn)
+        got8 = [t.float().cpu() for t in m(x.cuda())]
+    assert float((got16[0] - want[0]).abs().mean()) < 0.02
+    assert float((got8[0] - got16[0]).abs().mean()) < 0.05 and torch.isfinite(got8[0]).all()
+    # head-only checkpoint into a model whose backbone keeps its own weights
+    m2 = fresh()
+    m2.backbone.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")})
+    msg = inference.load_weights(m2, head_path, "head")
+    assert not msg.missing_keys and not msg.unexpected_keys
+    m2 = m2.cuda().eval()
+    with torch.no_grad():
+        got2 = m2(x.cuda())
+    for a, b in zip(got, got2):
+        assert torch.equal(a, b)
+    # a whole-module pickle is refused by the safe loader unless explicitly trusted
+    torch.save(src, tmp_path / "module.pth")
+    with pytest.raises(RuntimeError):
+        inference.load_weights(fresh(), tmp_path / "module.pth", "full")
