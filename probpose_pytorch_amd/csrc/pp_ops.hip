@@ -89,6 +89,102 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int c = lane; c < C; c += 64) Store<T>::st(orow + c, (xr[c] - mean) * rstd * gamma[c] + beta[c]);
 }
 
+// Multi-row form (C % 4 == 0, C <= NV * 256): a wave normalises RPW consecutive rows and issues ALL their loads
+// before the first reduction (RPW x NV x 16 B per lane in flight), and the launch is sized in whole rounds of
+// workgroups (ViT-B bs 64: 12 288 rows = 256 CUs x 4 workgroups x 4 waves x 3 rows).  The one-row form above ran
+// 3 072 workgroups on 2 048 slots -- 1.5 rounds, the second half empty -- at 3.8 TB/s; the arithmetic (two-pass
+// statistics in the same order) is unchanged, so results are bit-identical.
+template <typename T, int RPW, int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float *__restrict__ x,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, float eps, int rows,
+                                                             int C, T *__restrict__ out, float qscale) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  float4 v[RPW][NV];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const float *xr = x + (size_t)min(row0 + r, rows - 1) * C;     // tail rows re-read the last row (not stored)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) v[r][i] = *reinterpret_cast<const float4 *>(xr + c);
+    }
+  }
+  float4 g[NV], bt[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      g[i] = *reinterpret_cast<const float4 *>(gamma + c);
+      bt[i] = *reinterpret_cast<const float4 *>(beta + c);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) s += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        const float a = v[r][i].x - mean, b = v[r][i].y - mean, cc = v[r][i].z - mean, d = v[r][i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    if (row0 + r >= rows) continue;
+    T *orow = out + (size_t)(row0 + r) * C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        const float o0 = (v[r][i].x - mean) * rstd * g[i].x + bt[i].x, o1 = (v[r][i].y - mean) * rstd * g[i].y + bt[i].y,
+                    o2 = (v[r][i].z - mean) * rstd * g[i].z + bt[i].z, o3 = (v[r][i].w - mean) * rstd * g[i].w + bt[i].w;
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<float4 *>(orow + c) = make_float4(o0, o1, o2, o3);
+        } else if constexpr (sizeof(T) == 1) {
+          *reinterpret_cast<unsigned *>(orow + c) = ln_pack_fp8x4(o0 * qscale, o1 * qscale, o2 * qscale, o3 * qscale);
+        } else {
+          ushort4 pk;
+          pk.x = f32_to_bf16(o0); pk.y = f32_to_bf16(o1); pk.z = f32_to_bf16(o2); pk.w = f32_to_bf16(o3);
+          *reinterpret_cast<ushort4 *>(orow + c) = pk;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static bool layernorm_rows_launch(const float *x, const float *gamma, const float *beta, float eps, int rows, int C,
+                                  T *out, float qscale, hipStream_t s) {
+  if ((C & 3) != 0 || C > 1280 || C <= 512 || rows < 2048) return false;   // narrow rows: the one-row form is faster (measured at C = 384)
+#ifdef PP_LN_ONE_ROW
+  return false;
+#endif
+  // rows per wave: as close as the variants allow to one round of 4 workgroups (16 waves) per CU on 256 CUs
+  const int want = (rows + 4095) / 4096;
+  const int rpw = want >= 3 ? 3 : (want >= 2 ? 2 : 1);
+  const int grid = cdiv(rows, 4 * rpw);
+#define PP_LN_ROWS(RPW_, NV_)                                                                                     \
+  hipLaunchKernelGGL((layernorm_rows_kernel<T, RPW_, NV_>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C, \
+                     out, qscale)
+  if (C <= 768) {
+    if (rpw == 3) PP_LN_ROWS(3, 3); else if (rpw == 2) PP_LN_ROWS(2, 3); else PP_LN_ROWS(1, 3);
+  } else {
+    if (rpw == 3) PP_LN_ROWS(3, 5); else if (rpw == 2) PP_LN_ROWS(2, 5); else PP_LN_ROWS(1, 5);
+  }
+#undef PP_LN_ROWS
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // Patch im2col (+cast): NCHW fp32 image -> rows of 3*p*p, k = c*p*p + py*p + px.
 // ---------------------------------------------------------------------------
@@ -482,14 +578,17 @@ extern "C" int pp_layernorm(const float *x, const float *gamma, const float *bet
   PP_REQUIRE(x && gamma && beta && out, "pp_layernorm: null pointer");
   hipStream_t s = (hipStream_t)stream;
   const int grid = cdiv(rows, 4);
-  if (dtype == PP_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C,
-                       (bf16_t *)out);
-  else if (dtype == PP_F32)
-    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C,
-                       (float *)out);
-  else
+  if (dtype == PP_BF16) {
+    if (!layernorm_rows_launch<bf16_t>(x, gamma, beta, eps, rows, C, (bf16_t *)out, 1.0f, s))
+      hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C,
+                         (bf16_t *)out);
+  } else if (dtype == PP_F32) {
+    if (!layernorm_rows_launch<float>(x, gamma, beta, eps, rows, C, (float *)out, 1.0f, s))
+      hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, rows, C,
+                         (float *)out);
+  } else {
     return fail("pp_layernorm: bad dtype %d", dtype);
+  }
   PP_CHECK_LAUNCH("layernorm_kernel");
   return 0;
 }
@@ -500,8 +599,9 @@ extern "C" int pp_layernorm_fp8(const float *x, const float *gamma, const float 
   PP_REQUIRE(inv_scale > 0.f, "pp_layernorm_fp8: inv_scale must be positive");
   if (rows == 0) return 0;
   PP_REQUIRE(x && gamma && beta && out, "pp_layernorm_fp8: null pointer");
-  hipLaunchKernelGGL(layernorm_kernel<unsigned char>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
-                     beta, eps, rows, C, out, inv_scale);
+  if (!layernorm_rows_launch<unsigned char>(x, gamma, beta, eps, rows, C, out, inv_scale, (hipStream_t)stream))
+    hipLaunchKernelGGL(layernorm_kernel<unsigned char>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma,
+                       beta, eps, rows, C, out, inv_scale);
   PP_CHECK_LAUNCH("layernorm_kernel<fp8>");
   return 0;
 }

@@ -6,9 +6,14 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from probpose_pytorch_amd import ops
+from probpose_pytorch_amd import _lib, ops
 
-for rows, C in ((12288, 768), (49152, 1024), (12288, 384)):
+if "--lib" in sys.argv:      # A/B an experimental build (tools/build_exp.sh <name> [flags]); one library per process
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "probpose_pytorch_amd",
+                                 "lib", "exp", sys.argv[sys.argv.index("--lib") + 1])
+    print("library:", _lib.LIB_PATH)
+
+for rows, C in ((12288, 768), (49152, 1024), (12288, 384), (55296, 1280)):
     x = torch.randn((rows, C), device="cuda")
     g = torch.randn((C,), device="cuda")
     b = torch.randn((C,), device="cuda")
