@@ -138,6 +138,13 @@ typedef struct pp_gemm_args {
                                    6 = 192x192 wave-specialised (8 MFMA + 4 DMA waves, 3 stages),
                                    7 = 192x384, 8 = 256x256, 9 = 192x256 (8 waves, 2 stages; bf16) */
   float out_scale;              /* PP_EPI_OUT_FP8: 1 / (scale of the fp8 output tensor) */
+  int splitk;                   /* 0 / 1 = off.  S > 1: the launch computes S partial products per batch entry, split s
+                                   over the K range [s * Kd, (s + 1) * Kd) (Kd = the PER-SPLIT depth): operands advance
+                                   by the *_k strides below, the f32 partials go to C + s * strideC_k and are summed by
+                                   the consumer (pp_maxpool_relu_sum).  Only with epilogue == PP_EPI_OUT_F32 (no bias,
+                                   activation or residual); gather segments must not straddle a split (Kd % seg_len == 0).
+                                   Used for the long-K, few-row aux convolutions (head.py:255-405 stages 2, 3). */
+  long long strideA_k, strideW_k, strideC_k, strideRowoff_k;   /* elements per split step */
 } pp_gemm_args;
 int pp_gemm(const pp_gemm_args *args, void *stream);
 
@@ -163,6 +170,12 @@ int pp_attention_fp8out(const void *qkv, unsigned char *out, int B, int N, int h
  * the A operand of patch_embed.proj as a GEMM (timm PatchEmbed, stride = patch). */
 int pp_patchify(const float *x, void *out, int B, int H, int W, int patch, int dtype,
                 void *stream);
+
+/* Split-K consumer of the aux convolutions: x = nsplit f32 partial maps [nsplit][B, h, w, C] (split stride
+ * `split_stride` elements), bias [C] f32 -> out [B, h/kh, w/kw, C] in `dtype` = ReLU(MaxPool(sum_s x_s + bias))
+ * (head.py:271-276 behind a conv whose K was split over workgroups). */
+int pp_maxpool_relu_sum(const float *x, int nsplit, long long split_stride, const float *bias, void *out, int B, int h,
+                        int w, int C, int kh, int kw, int dtype, void *stream);
 
 /* MaxPool(kh,kw stride kh,kw) + ReLU on channels-last rows (head.py:271-276):
  * x [B, h, w, C] -> out [B, h/kh, w/kw, C]. */

@@ -37,6 +37,9 @@ class GemmArgs(C.Structure):
         ("C2", C.c_void_p), ("ldc2", C.c_int), ("stats_out", C.c_void_p), ("stats_in", C.c_void_p),
         ("stats_parts", C.c_int), ("colsum", C.c_void_p), ("ln_eps", C.c_float), ("tile", C.c_int),
         ("out_scale", C.c_float),
+        ("splitk", C.c_int),
+        ("strideA_k", C.c_longlong), ("strideW_k", C.c_longlong), ("strideC_k", C.c_longlong),
+        ("strideRowoff_k", C.c_longlong),
     ]
 
 
@@ -54,6 +57,7 @@ _SIGNATURES = {
     "pp_attention_fp8out": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pp_maxpool_relu_sum": (C.c_int, [_vp, _i, C.c_longlong, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "pp_final_heatmap": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "pp_final_logits": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "pp_sparsemax_rows": (C.c_int, [_vp, C.c_longlong, _i, _f, _vp]),

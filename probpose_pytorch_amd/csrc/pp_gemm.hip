@@ -75,6 +75,8 @@ struct GemmParams {
   int lda, ldw, ldc;
   int seg_len, rowbias_period;
   long long strideA, strideW, strideC, strideBias, strideRowoff, strideRowmap;
+  int splitk;        // K splits per batch entry (grid.y = batch * splitk)
+  long long strideA_k, strideW_k, strideC_k, strideRowoff_k;
   int epilogue;
   int hm_K, hm_HW;
   float hm_temperature;
@@ -218,10 +220,12 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     tn = blockIdx.x - tm * p.tiles_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z = blockIdx.y;
-  const char *Ab = p.A + (size_t)z * p.strideA * ES;
-  const char *Wb = p.W + (size_t)z * p.strideW * ES;
-  const int32_t *rowoff = GATHER ? p.rowoff + (size_t)z * p.strideRowoff : nullptr;
+  // grid.y = batch entry x K split: split zs multiplies the K range [zs * Kd, (zs + 1) * Kd) into its own f32 partial
+  const int zs = p.splitk > 1 ? (int)(blockIdx.y % p.splitk) : 0;
+  const int z = p.splitk > 1 ? (int)(blockIdx.y / p.splitk) : (int)blockIdx.y;
+  const char *Ab = p.A + ((size_t)z * p.strideA + (size_t)zs * p.strideA_k) * ES;
+  const char *Wb = p.W + ((size_t)z * p.strideW + (size_t)zs * p.strideW_k) * ES;
+  const int32_t *rowoff = GATHER ? p.rowoff + (size_t)z * p.strideRowoff + (size_t)zs * p.strideRowoff_k : nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool is_producer = NWP > 0 && __builtin_amdgcn_readfirstlane(wave) >= NW;
@@ -944,7 +948,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
   // operand, so a 16x16 accumulator tile holds C^T: lane (frow, fq) owns output row m = .. + frow and
   // the 4 CONSECUTIVE columns n = .. + 4*fq + e -> 8-byte (bf16) / 16-byte (fp32) vector stores.
   // All additive terms are already in the accumulators: activation, convert, store.
-  char *Cb = p.C + (size_t)z * p.strideC *
+  char *Cb = p.C + ((size_t)z * p.strideC + (size_t)zs * p.strideC_k) *
                        ((epi & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP)) ? 4 : (ES == 1 ? ((epi & PP_EPI_OUT_FP8) ? 1 : 2) : ES));
   bool stored = false;
   if constexpr (VEC) {
@@ -1551,6 +1555,14 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.rowbias_period = a->rowbias_period;
   p.strideA = a->strideA; p.strideW = a->strideW; p.strideC = a->strideC;
   p.strideBias = a->strideBias; p.strideRowoff = a->strideRowoff; p.strideRowmap = a->strideRowmap;
+  p.splitk = a->splitk > 1 ? a->splitk : 1;
+  p.strideA_k = a->strideA_k; p.strideW_k = a->strideW_k; p.strideC_k = a->strideC_k; p.strideRowoff_k = a->strideRowoff_k;
+  if (p.splitk > 1) {
+    PP_REQUIRE(a->epilogue == PP_EPI_OUT_F32 && a->dtype != PP_FP8 && !a->out_rowmap,
+               "pp_gemm: split-K launches write plain f32 partials (epilogue must be PP_EPI_OUT_F32 alone)");
+    PP_REQUIRE(!a->rowoff || a->Kd % (a->seg_len > 0 ? a->seg_len : a->Kd) == 0,
+               "pp_gemm: split-K depth %d must be a whole number of gather segments (%d)", a->Kd, a->seg_len);
+  }
   p.epilogue = a->epilogue;
   p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
   p.C2 = (char *)a->C2; p.ldc2 = a->ldc2; p.stats_out = a->stats_out; p.stats_in = a->stats_in;
@@ -1564,7 +1576,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   } else {
     PP_REQUIRE(!(a->epilogue & PP_EPI_OUT_FP8), "pp_gemm: PP_EPI_OUT_FP8 is an fp8-GEMM epilogue");
   }
-  const int batch = a->batch > 0 ? a->batch : 1;
+  const int batch = (a->batch > 0 ? a->batch : 1) * (a->splitk > 1 ? a->splitk : 1);   // grid.y
   PP_REQUIRE(batch <= 65535, "pp_gemm: batch too large");
   // Tile configuration.  0 = auto, 1 = 128x128 (4 waves, 2 stages), 2 = 192x96 (4 waves, 2 stages),
   // 3 = 192x192 (8 waves, 3 stages, one workgroup per CU), 4 = 192x128 (8 waves, 3 stages),

@@ -249,6 +249,51 @@ __global__ __launch_bounds__(256) void maxpool_relu_kernel(const T *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// Split-K consumer: the same pooling on the SUM of nsplit f32 partial maps (+ bias), 16 B (4 channels) per lane.
+// The aux convolutions after the first pooling have few rows (M = 16 B, 4 B) and K = 9 C: as one GEMM they fill a
+// fraction of the chip with 108 sequential K-tiles per workgroup (measured 104 / 99 us at 418 / 109 TFLOP/s); split
+// over K into workgroups their partials are reduced here, where the map is read anyway.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_relu_sum_kernel(const float *__restrict__ x, int nsplit,
+                                                               long long split_stride, const float *__restrict__ bias,
+                                                               T *__restrict__ out, int B, int h, int w, int C, int kh,
+                                                               int kw) {
+  const int oh = h / kh, ow = w / kw, CV = C / 4;
+  const long long total = (long long)B * oh * ow * CV;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    long long t = i / CV;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const int b = (int)(t / oh);
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + cv * 4);
+    float m[4] = {0.f, 0.f, 0.f, 0.f};                 // ReLU folded in: max(0, max(window))
+    for (int dy = 0; dy < kh; ++dy)
+      for (int dx = 0; dx < kw; ++dx) {
+        const float *src = x + (((size_t)b * h + oy * kh + dy) * w + ox * kw + dx) * C + cv * 4;
+        float4 a = *reinterpret_cast<const float4 *>(src);
+        for (int sp = 1; sp < nsplit; ++sp) {          // split order 0, 1, 2, ...: a fixed summation order
+          const float4 q = *reinterpret_cast<const float4 *>(src + (size_t)sp * split_stride);
+          a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        }
+        const float f[4] = {a.x + bv.x, a.y + bv.y, a.z + bv.z, a.w + bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = (f[e] > m[e] || f[e] != f[e]) ? f[e] : m[e];
+      }
+    T *o = out + (((size_t)b * oh + oy) * ow + ox) * C + cv * 4;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4 *>(o) = make_float4(m[0], m[1], m[2], m[3]);
+    } else {
+      ushort4 pk;
+      pk.x = f32_to_bf16(m[0]); pk.y = f32_to_bf16(m[1]); pk.z = f32_to_bf16(m[2]); pk.w = f32_to_bf16(m[3]);
+      *reinterpret_cast<ushort4 *>(o) = pk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Aux tail: per branch 1x1 conv C->K on the pooled 1x1 feature + Sigmoid/ReLU.
 // x [B, nbr*C] (branch-major columns), w [nbr][K][C], bias [nbr][K], out [nbr][B][K].
 // One wave per output value.
@@ -664,6 +709,27 @@ extern "C" int pp_aux_tail(const void *x, const void *w, const float *bias, floa
   else
     return fail("pp_aux_tail: bad dtype %d", dtype);
   PP_CHECK_LAUNCH("aux_tail_kernel");
+  return 0;
+}
+
+extern "C" int pp_maxpool_relu_sum(const float *x, int nsplit, long long split_stride, const float *bias, void *out,
+                                   int B, int h, int w, int C, int kh, int kw, int dtype, void *stream) {
+  PP_REQUIRE(B >= 0 && h > 0 && w > 0 && C > 0 && kh > 0 && kw > 0 && nsplit >= 1, "pp_maxpool_relu_sum: bad shape");
+  PP_REQUIRE(h / kh > 0 && w / kw > 0, "pp_maxpool_relu_sum: window %dx%d larger than input %dx%d", kh, kw, h, w);
+  if (B == 0) return 0;
+  PP_REQUIRE(x && bias && out, "pp_maxpool_relu_sum: null pointer");
+  PP_REQUIRE(C % 4 == 0 && split_stride % 4 == 0, "pp_maxpool_relu_sum: C and the split stride must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for((long long)B * (h / kh) * (w / kw) * (C / 4));
+  if (dtype == PP_BF16)
+    hipLaunchKernelGGL(maxpool_relu_sum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, nsplit, split_stride, bias,
+                       (bf16_t *)out, B, h, w, C, kh, kw);
+  else if (dtype == PP_F32)
+    hipLaunchKernelGGL(maxpool_relu_sum_kernel<float>, dim3(grid), dim3(256), 0, s, x, nsplit, split_stride, bias,
+                       (float *)out, B, h, w, C, kh, kw);
+  else
+    return fail("pp_maxpool_relu_sum: bad dtype %d", dtype);
+  PP_CHECK_LAUNCH("maxpool_relu_sum_kernel");
   return 0;
 }
 

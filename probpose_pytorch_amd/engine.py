@@ -37,6 +37,8 @@ FUSE_LAYERNORM = False
 FP8_PROJ = False
 DUAL_CHAIN = False
 DUAL_CHAIN_MIN_BATCH = 16
+# aux stages >= 1 (M = 16 B / 4 B rows, K = 9 C) as split-K launches with the reduction folded into the pooling kernel
+SPLITK_AUX = True
 
 
 def _signature(module: torch.nn.Module):
@@ -493,13 +495,31 @@ class HeadPlan:
                 if i == 0:
                     ops.gemm(a, self.aux_w[0], conv, M=M, N=4 * C, Kd=9 * C, lda=C, ldw=9 * C, ldc=4 * C,
                              bias=self.aux_b[0], rowoff=ro, seg_len=C)
+                    split = 1
                 else:
-                    ops.gemm(a, self.aux_w[i], conv, M=M, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
-                             bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,
-                             strideC=C, strideBias=C)
+                    # few rows (16 B, then 4 B) against K = 9 C: split the taps over workgroups when the plain launch
+                    # would leave most CUs idle behind 108 sequential K-tiles (S f32 partials, summed in the pooling)
+                    tiles = 4 * ((M + 191) // 192) * ((C + 191) // 192)
+                    split = 9 if tiles <= 40 else (3 if tiles <= 130 else 1)
+                    if not SPLITK_AUX:
+                        split = 1
+                    if split == 1:
+                        ops.gemm(a, self.aux_w[i], conv, M=M, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
+                                 bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,
+                                 strideC=C, strideBias=C)
+                    else:
+                        parts = g(f"aux_part{i}", (split, M, 4 * C), torch.float32, dev)
+                        taps = 9 // split
+                        ops.gemm(a, self.aux_w[i], parts, M=M, N=C, Kd=taps * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
+                                 rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C,
+                                 epilogue=EPI_OUT_F32, splitk=split, strideW_k=taps * C, strideRowoff_k=taps * M,
+                                 strideC_k=M * 4 * C)
                 kh, kw, oh, ow = pack.pool_out(ah, aw, p)
                 pooled = g(f"aux_pool{i}", (B * oh * ow, 4 * C), dt, dev)
-                ops.maxpool_relu(conv, pooled, B, ah, aw, 4 * C, kh, kw)
+                if split > 1:
+                    ops.maxpool_relu_sum(parts, self.aux_b[i].reshape(-1), pooled, B, ah, aw, 4 * C, kh, kw)
+                else:
+                    ops.maxpool_relu(conv, pooled, B, ah, aw, 4 * C, kh, kw)
                 a, ah, aw = pooled, oh, ow
             ops.aux_tail(a, self.tail_w, self.tail_b, aux, B, C, K)
         # ---- heatmap branch

@@ -117,7 +117,8 @@ def _tune(a, key, out, residual):
 def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
          strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0,
-         ln_producer=None, ln_consumer=None, colscale=None, out_scale=None):
+         ln_producer=None, ln_consumer=None, colscale=None, out_scale=None, splitk=1, strideA_k=0, strideW_k=0,
+         strideC_k=0, strideRowoff_k=0):
     """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h.
     fp8 (A, W torch.float8_e4m3fn): ``colscale`` [N] f32 = activation scale x weight-row scale; ``out`` may be
     bf16, f32 (with residual) or fp8 (then ``out_scale`` = the scale of the output tensor)."""
@@ -129,6 +130,7 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
     a.seg_len, a.rowbias_period, a.batch = seg_len, rowbias_period, batch
     a.strideA, a.strideW, a.strideC, a.strideBias = strideA, strideW, strideC, strideBias
     a.strideRowoff, a.strideRowmap = strideRowoff, strideRowmap
+    a.splitk, a.strideA_k, a.strideW_k, a.strideC_k, a.strideRowoff_k = splitk, strideA_k, strideW_k, strideC_k, strideRowoff_k
     a.dtype = dtype_code(W.dtype)
     if bias is not None:
         epilogue |= EPI_BIAS
@@ -166,14 +168,15 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
     a.epilogue = epilogue
     a.tile = tile
     if tile == 0 and AUTOTUNE and M * N * Kd >= (1 << 24):
-        key = (M, N, Kd, batch, a.dtype, rowoff is not None, out_rowmap is not None, epilogue, lda, ldw, ldc)
+        key = (M, N, Kd, batch * max(1, splitk), a.dtype, rowoff is not None, out_rowmap is not None, epilogue, lda, ldw, ldc)
         best = _TUNE_CACHE.get(key)
         if best is None and not torch.cuda.is_current_stream_capturing():
             best = _tune(a, key, out, residual)
         if best:
             a.tile = best
-    rc = _timed("gemm", 2.0 * M * N * Kd * batch, lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()),
-                f"M={M} N={N} K={Kd} batch={batch} gather={rowoff is not None} epi={epilogue}")
+    rc = _timed("gemm", 2.0 * M * N * Kd * batch * max(1, splitk),
+                lambda: _lib.lib().pp_gemm(C.byref(a), _lib.stream_ptr()),
+                f"M={M} N={N} K={Kd} batch={batch} splitk={splitk} gather={rowoff is not None} epi={epilogue}")
     _lib.check(rc, "pp_gemm")
     return out
 
@@ -239,6 +242,14 @@ def patchify(x, out, patch):
 def maxpool_relu(x, out, B, h, w, Cc, kh, kw):
     _lib.check(_lib.lib().pp_maxpool_relu(_p(x), _p(out), B, h, w, Cc, kh, kw, dtype_code(x.dtype),
                                           _lib.stream_ptr()), "pp_maxpool_relu")
+    return out
+
+
+def maxpool_relu_sum(parts, bias, out, B, h, w, Cc, kh, kw):
+    """parts [S, B*h*w, Cc] f32 split-K partials -> out = ReLU(MaxPool(sum_s parts[s] + bias))."""
+    S = parts.shape[0]
+    _lib.check(_lib.lib().pp_maxpool_relu_sum(_p(parts), S, parts.stride(0), _p(bias), _p(out), B, h, w, Cc, kh, kw,
+                                              dtype_code(out.dtype), _lib.stream_ptr()), "pp_maxpool_relu_sum")
     return out
 
 

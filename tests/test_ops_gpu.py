@@ -391,3 +391,38 @@ def test_attention_fp8_output(ops, B, N, heads, hd):
     err = (got - ref.float()).abs()
     assert bool((err <= ref.float().abs() * 2 ** -3 + scale * 2 ** -8).all())
     assert float(err.mean()) < float(ref.float().abs().mean()) * 0.05
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("split", [3, 9])
+def test_gemm_splitk_aux_conv_and_pool_sum(ops, dtype, split):
+    """Aux-branch stages >= 1 as split-K launches (taps split over workgroups, f32 partials) + the pooling kernel that
+    sums the partials, adds the bias, pools and applies ReLU: equals conv3x3 + bias -> MaxPool -> ReLU of torch."""
+    from probpose_pytorch_amd import pack
+    B, h, w, C = 3, 4, 4, 64
+    x = _rand((B * h * w, 4 * C), dtype, 1)
+    wt = _rand((4, C, C, 3, 3), torch.float32, 2, (9 * C) ** -0.5)
+    bias = _rand((4, C), torch.float32, 3)
+    Wp = torch.stack([pack.conv_taps_major(wt[i].cpu()) for i in range(4)]).to(dtype).cuda()
+    ro = pack.conv_gather_table(B, h, w, 3, 3, 1, 1, 4 * C).cuda()
+    M = B * h * w
+    taps = 9 // split
+    for tile in (0, 2, 3, 4, 10):
+        parts = torch.full((split, M, 4 * C), float("nan"), dtype=torch.float32, device="cuda")
+        ops.gemm(x, Wp, parts, M=M, N=C, Kd=taps * C, lda=4 * C, ldw=9 * C, ldc=4 * C, rowoff=ro, seg_len=C, batch=4,
+                 strideA=C, strideW=C * 9 * C, strideC=C, epilogue=ops.EPI_OUT_F32, splitk=split, strideW_k=taps * C,
+                 strideRowoff_k=taps * M, strideC_k=M * 4 * C, tile=tile)
+        conv = parts.sum(0) + bias.reshape(-1)
+        out = torch.empty_like(conv).to(dtype)
+        out.copy_(conv)
+        _check_branches(x, Wp, bias, out, B, h, w, C, dtype)
+        pooled = torch.empty((B * 2 * 2, 4 * C), dtype=dtype, device="cuda")
+        ops.maxpool_relu_sum(parts, bias.reshape(-1).contiguous(), pooled, B, h, w, 4 * C, 2, 2)
+        ref = F.relu(F.max_pool2d(conv.reshape(B, h, w, 4 * C).permute(0, 3, 1, 2), 2)).permute(0, 2, 3, 1)
+        # the kernel adds the partials in split order, torch.sum pairwise: equal up to fp32 rounding of the sum
+        torch.testing.assert_close(pooled.float().reshape(B, 2, 2, 4 * C), ref.to(dtype).float(),
+                                   rtol=2e-6 if dtype == torch.float32 else 2 ** -7, atol=1e-6 if dtype == torch.float32 else 1e-2)
+    with pytest.raises(Exception):      # split-K launches carry no bias / activation
+        ops.gemm(x, Wp, parts, M=M, N=C, Kd=taps * C, lda=4 * C, ldw=9 * C, ldc=4 * C, rowoff=ro, seg_len=C, batch=4,
+                 strideA=C, strideW=C * 9 * C, strideC=C, bias=bias, epilogue=ops.EPI_OUT_F32, splitk=split,
+                 strideW_k=taps * C, strideRowoff_k=taps * M, strideC_k=M * 4 * C)
