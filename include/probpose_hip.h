@@ -54,6 +54,10 @@ extern "C" {
                                            from stats_in (exactly LN(x) W^T + b in exact arithmetic)                */
 #define PP_EPI_OUT_FP8 512              /* fp8 GEMM only: store e4m3(value * out_scale) instead of bf16 (the next fp8 GEMM's A) */
 #define PP_EPI_NOCLAMP 1024             /* with PP_EPI_HEATMAP: store v / temperature unclamped (the Sparsemax path, head.py:526-528) */
+#define PP_EPI_FUSE_FINAL 2048           /* bf16, N = 256 (tile 9): the epilogue also applies the final 1x1 heatmap layer
+                                           (head.py:525-532) to the ReLU'd tile: C is the f32 NCHW heat buffer [B, hm_K, hm_HW],
+                                           final_w [hm_K, 256] bf16, final_b [hm_K] f32, hm_K <= 32; the 256-channel map is
+                                           never stored.  out_rowmap gives each GEMM row its pixel index b * hm_HW + hw. */
 #define PP_EPI_HEATMAP 64               /* head.py:526-532: f32 NCHW store of clamp(v / temperature, 0, 1):
                                            C[((r / hm_HW) * hm_K + n) * hm_HW + r % hm_HW], r = output row */
 
@@ -145,6 +149,8 @@ typedef struct pp_gemm_args {
                                    activation or residual); gather segments must not straddle a split (Kd % seg_len == 0).
                                    Used for the long-K, few-row aux convolutions (head.py:255-405 stages 2, 3). */
   long long strideA_k, strideW_k, strideC_k, strideRowoff_k;   /* elements per split step */
+  const void *final_w;          /* PP_EPI_FUSE_FINAL */
+  const float *final_b;
 } pp_gemm_args;
 int pp_gemm(const pp_gemm_args *args, void *stream);
 

@@ -31,7 +31,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROW_BYTES = 128;                 // bytes of K per staged row
-constexpr int gemm_lds_bytes(int BM, int BN, int stages) { return stages * (BM + BN) * ROW_BYTES; }
+constexpr int FUSE_MAPS = 32;                   // keypoint maps the fused final 1x1 layer serves (two 16-wide MFMA tiles)
+constexpr int gemm_lds_bytes(int BM, int BN, int stages) {
+  const int ring = stages * (BM + BN) * ROW_BYTES;
+  // 192 x 256 (the N = 256 deconvolution layers): C staging + row map + the final layer's weight image (PP_EPI_FUSE_FINAL)
+  const int fused = BM * (BN * 2 + 16) + BM * 4 + FUSE_MAPS * (BN * 2 + 16);
+  return (BM == 192 && BN == 256 && fused > ring) ? fused : ring;
+}
 
 // Diagnostic build only (-DPP_GEMM_STAMPS, never shipped): per-wave cycle shares of the K-loop
 // phases are written to the buffer passed in GemmParams::rowbias when epilogue bit 30 is set.
@@ -92,6 +98,8 @@ struct GemmParams {
   int blocked;       // XCD-blocked tile order (large grids) vs plain order
   int rn;            // column tiles per XCD block (<= tiles_n, so narrow-N launches carry no empty slots)
   int lds_epilogue;  // bf16 C tile staged through LDS and stored as whole rows
+  const char *final_w;     // PP_EPI_FUSE_FINAL: [hm_K, N] storage-dtype weights of the 1x1 heatmap layer
+  const float *final_b;    // [hm_K]
 };
 
 // LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte offset (M0) + lane * 16.  Issued
@@ -1031,6 +1039,54 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
             }
           }
         }
+        if constexpr (BM == 192 && BN == 256 && OES == 2 && sizeof(T) == 2 && NPASS == 1 && NWP == 0) {
+          if (epi & PP_EPI_FUSE_FINAL) {
+            // ---- fused final 1x1 layer (head.py:525-532): the ReLU'd bf16 tile just staged (192 pixels x all 256
+            // channels) is multiplied by the K <= 32 keypoint maps' weights right here -- a 192 x 32 x 256 product on
+            // the matrix cores, A = pixels from the staging rows, B = the weight image loaded beside them -- then
+            // bias, / temperature, clamp and the NCHW float32 store.  The 256-channel 64x48 map (100 MB at bs 64) is
+            // never written to HBM nor read back, and the separate final-layer launch disappears.  Same k order and
+            // same bf16-rounded operands as final_heatmap_mfma_kernel: bit-identical heatmaps.
+            constexpr int WFS = BN * 2 + 16;
+            char *wimg = smem + BM * CS + BM * 4;
+            for (int c = tid; c < FUSE_MAPS * (BN / 8); c += NTHREADS_EPI) {
+              const int k = c / (BN / 8), ch = c - k * (BN / 8);
+              uint4 v = make_uint4(0, 0, 0, 0);
+              if (k < p.hm_K) v = *reinterpret_cast<const uint4 *>(p.final_w + ((size_t)k * BN + ch * 8) * 2);
+              *reinterpret_cast<uint4 *>(wimg + k * WFS + ch * 16) = v;
+            }
+            __syncthreads();
+            const int prow_ = lane & 15, kq = lane >> 4;
+            float *heat = reinterpret_cast<float *>(p.C);
+            const int HW = p.hm_HW, KK = p.hm_K;
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+              const int t = wave * 3 + tt, rt = t >> 1, ct = t & 1;
+              f32x4 a2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int s2 = 0; s2 < BN / 32; ++s2) {
+                const uint4 av = *reinterpret_cast<const uint4 *>(smem + (rt * 16 + prow_) * CS + (4 * s2 + kq) * 16);
+                const uint4 bv = *reinterpret_cast<const uint4 *>(wimg + (ct * 16 + prow_) * WFS + (4 * s2 + kq) * 16);
+                a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8 *>(&av),
+                                                             *reinterpret_cast<const bf16x8 *>(&bv), a2, 0, 0, 0);
+              }
+              const int k = ct * 16 + prow_;            // accumulator: pixels 4 kq + e (rows) of map k (column)
+              if (k < KK) {
+                const float fbk = p.final_b[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const int r = rows_lds[rt * 16 + 4 * kq + e];
+                  if (r < 0) continue;
+                  float x = (a2[e] + fbk) / p.hm_temperature;
+                  if (!(epi & PP_EPI_NOCLAMP)) x = fminf(fmaxf(x, 0.f), 1.f);
+                  const int b_ = r / HW, hw = r - b_ * HW;
+                  heat[((size_t)b_ * KK + k) * HW + hw] = x;
+                }
+              }
+            }
+            continue;       // nothing else to store for this tile (NPASS == 1: leaves the pass loop)
+          }
+        }
         __syncthreads();
         constexpr int CPR = PBN * OES / 16;           // 16-B chunks per row
         const int ncols16 = max(0, min(CPR, (p.N - n0 - pass * PBN) * OES / 16));
@@ -1540,6 +1596,13 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
              "pp_gemm: a GEMM is either a LayerNorm producer or a consumer");
   if (a->epilogue & PP_EPI_HEATMAP)
     PP_REQUIRE(a->hm_K >= a->N && a->hm_HW > 0 && a->hm_temperature != 0.f, "pp_gemm: bad heatmap epilogue");
+  if (a->epilogue & PP_EPI_FUSE_FINAL) {
+    PP_REQUIRE(a->dtype == PP_BF16 && a->N == 256 && a->final_w && a->final_b && a->hm_K > 0 && a->hm_K <= 32 &&
+                   a->hm_HW > 0 && a->hm_temperature != 0.f && (a->tile == 9 || a->tile == 0) &&
+                   !(a->epilogue & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP | PP_EPI_RESIDUAL | PP_EPI_ROWSTATS | PP_EPI_LNFOLD)) &&
+                   ((uintptr_t)a->final_w & 15) == 0,
+               "pp_gemm: PP_EPI_FUSE_FINAL serves bf16 layers with N = 256 outputs (tile 9), K <= 32 keypoint maps");
+  }
   GemmParams p;
   p.A = (const char *)a->A;
   p.W = (const char *)a->W;
@@ -1568,6 +1631,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.C2 = (char *)a->C2; p.ldc2 = a->ldc2; p.stats_out = a->stats_out; p.stats_in = a->stats_in;
   p.stats_parts = a->stats_parts; p.colsum = a->colsum; p.ln_eps = a->ln_eps;
   p.out_scale = a->out_scale;
+  p.final_w = (const char *)a->final_w; p.final_b = a->final_b;
   if (a->dtype == PP_FP8) {
     PP_REQUIRE(a->colsum && !a->rowoff && !a->out_rowmap && !(a->epilogue & (PP_EPI_ROWSTATS | PP_EPI_LNFOLD | PP_EPI_ROWBIAS | PP_EPI_HEATMAP)),
                "pp_gemm: fp8 needs colsum = per-column dequantisation scales and a plain (non-gather, non-fused) GEMM");
@@ -1591,6 +1655,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   };
   const bool vec = (a->N & 3) == 0 && (a->ldc & 3) == 0 && !(a->epilogue & PP_EPI_HEATMAP);
   int cfg = vec ? a->tile : 1;
+  if (a->epilogue & PP_EPI_FUSE_FINAL) cfg = 9;     // the one configuration that holds all 256 channels of a pixel
   if (cfg == 0) {
     const double c1 = (double)rounds(128, 128, 512) * 128 * 128 * 2;   // 2 workgroups share a CU
     const double c2 = (double)rounds(192, 96, 512) * 192 * 96 * 2;

@@ -39,6 +39,8 @@ DUAL_CHAIN = False
 DUAL_CHAIN_MIN_BATCH = 16
 # aux stages >= 1 (M = 16 B / 4 B rows, K = 9 C) as split-K launches with the reduction folded into the pooling kernel
 SPLITK_AUX = True
+# bf16 heads with K <= 32 keypoints: the last deconvolution's epilogue applies the final 1x1 layer (see HeadPlan._forward)
+FUSE_FINAL = True
 
 
 def _signature(module: torch.nn.Module):
@@ -524,8 +526,23 @@ class HeadPlan:
             ops.aux_tail(a, self.tail_w, self.tail_b, aux, B, C, K)
         # ---- heatmap branch
         x, hh, ww, cin = feats, h, w, C
+        f = self.final
+        clamp = self.normalize is None
+        fused_final = False
         for li, (d, (ro, rm, _, _)) in enumerate(zip(self.deconvs, tb["deconv"])):
             M = B * hh * ww
+            last = li == len(self.deconvs) - 1
+            if (FUSE_FINAL and last and not self.convs and dt == torch.bfloat16 and d["cout"] == 256 and f["k"] == 1
+                    and K <= 32):
+                # the last deconvolution's epilogue applies the final 1x1 layer itself: its 256-channel output
+                # (100 MB at bs 64) is never stored, and the final-layer launch is gone
+                ops.gemm(x, d["w"], heat, M=M, N=256, Kd=4 * cin, lda=cin, ldw=4 * cin, ldc=256, bias=d["b"],
+                         rowoff=ro, seg_len=cin, out_rowmap=rm, batch=4, strideW=256 * 4 * cin, strideRowoff=4 * M,
+                         strideRowmap=M, epilogue=EPI_RELU,
+                         fuse_final=(f["w"], f["b"], K, 4 * hh * ww, self.temperature, clamp))
+                fused_final = True
+                hh, ww, cin = 2 * hh, 2 * ww, 256
+                break
             out = g(f"deconv{li}", (4 * M, d["cout"]), dt, dev)
             ops.gemm(x, d["w"], out, M=M, N=d["cout"], Kd=4 * cin, lda=cin, ldw=4 * cin, ldc=d["cout"],
                      bias=d["b"], rowoff=ro, seg_len=cin, out_rowmap=rm, batch=4,
@@ -540,11 +557,11 @@ class HeadPlan:
             x, cin = out, c["cout"]
         M = B * hh * ww
         assert heat.shape == (B, K, hh, ww)
-        f = self.final
         kk = f["k"] * f["k"]
         es = 2 if dt == torch.bfloat16 else 4
-        clamp = self.normalize is None
-        if f["k"] == 1 and 64 * (cin * es + 16) + K * cin * es <= 150 * 1024:
+        if fused_final:
+            pass
+        elif f["k"] == 1 and 64 * (cin * es + 16) + K * cin * es <= 150 * 1024:
             ops.final_heatmap(x, f["w"], f["b"], heat, B, hh * ww, cin, K, self.temperature, clamp=clamp)
         else:
             ops.gemm(x, f["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=f["b"],

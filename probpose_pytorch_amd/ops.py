@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_GELU, EPI_HEATMAP, EPI_LNFOLD, EPI_NOCLAMP, EPI_OUT_F32, EPI_OUT_FP8, EPI_RELU,  # noqa: F401
+from ._lib import (EPI_BIAS, EPI_FUSE_FINAL, EPI_GELU, EPI_HEATMAP, EPI_LNFOLD, EPI_NOCLAMP, EPI_OUT_F32, EPI_OUT_FP8, EPI_RELU,  # noqa: F401
                    EPI_RESIDUAL, EPI_ROWBIAS, EPI_ROWSTATS, PP_BF16, PP_F32, PP_FP8)
 
 FP8 = torch.float8_e4m3fn          # OCP e4m3: what gfx950's fp8 MFMA and conversions use
@@ -118,7 +118,7 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
          strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0,
          ln_producer=None, ln_consumer=None, colscale=None, out_scale=None, splitk=1, strideA_k=0, strideW_k=0,
-         strideC_k=0, strideRowoff_k=0):
+         strideC_k=0, strideRowoff_k=0, fuse_final=None):
     """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h.
     fp8 (A, W torch.float8_e4m3fn): ``colscale`` [N] f32 = activation scale x weight-row scale; ``out`` may be
     bf16, f32 (with residual) or fp8 (then ``out_scale`` = the scale of the output tensor)."""
@@ -143,6 +143,12 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         a.hm_K, a.hm_HW, a.hm_temperature = heatmap[:3]
         if len(heatmap) > 3 and not heatmap[3]:
             epilogue |= EPI_NOCLAMP
+    if fuse_final is not None:    # (final_w [K, 256], final_b [K], K, HW, temperature, clamp): out = heat [B, K, HW] f32
+        fw, fb, fk, fhw, ftemp, fclamp = fuse_final
+        epilogue |= EPI_FUSE_FINAL | (0 if fclamp else EPI_NOCLAMP)
+        a.final_w, a.final_b = _p(fw), _p(fb)
+        a.hm_K, a.hm_HW, a.hm_temperature = fk, fhw, ftemp
+        tile = 9
     if ln_producer is not None:
         # LayerNorm fusion, producer: (c2 copy [M, N] in the storage dtype or None, stats [M, parts, 2]);
         # the 192-wide column tile fixes the number of partials per row

@@ -498,3 +498,23 @@ def test_checkpoint_interop_state_dict_roundtrip(pkg, tmp_path):
     torch.save(src, tmp_path / "module.pth")
     with pytest.raises(RuntimeError):
         inference.load_weights(fresh(), tmp_path / "module.pth", "full")
+
+
+def test_fused_final_layer_is_bit_identical(pkg, monkeypatch):
+    """engine.FUSE_FINAL: the last deconvolution's epilogue applies the final 1x1 layer (+ / T + clamp) instead of
+    storing its 256-channel map for a separate launch.  Same bf16-rounded operands, same k order: the heatmaps must be
+    bit-identical to the two-kernel path (and the aux outputs untouched)."""
+    from probpose_pytorch_amd import engine
+    for K, B in ((17, 5), (32, 2), (3, 1)):
+        head = pkg["head"].ProbMapHead(384, K, [(4, 3), (2, 2), (2, 2)], (256, 256), (4, 4), final_layer_kernel_size=1)
+        head.load_state_dict(pkg["syn"].synthetic_head_state(384, K, 3, (256, 256), seed=20 + K))
+        head = head.cuda().eval().set_compute_dtype(torch.bfloat16)
+        feats = pkg["syn"].synthetic_features(B, 384, 16, 12, seed=3).cuda()
+        with torch.no_grad():
+            monkeypatch.setattr(engine, "FUSE_FINAL", True)
+            fused = [t.clone() for t in head(feats)]
+            monkeypatch.setattr(engine, "FUSE_FINAL", False)
+            plain = [t.clone() for t in head(feats)]
+        assert fused[0].shape == (B, K, 64, 48) and float(fused[0].max()) > 0
+        for a, b in zip(fused, plain):
+            assert torch.equal(a, b)
