@@ -17,6 +17,8 @@
 //     (heatmap.py:114-167); compiled with -ffp-contract=off so no FMA fuses
 //     what numpy evaluates as separate float32 operations.
 //   * rescale in float64: locs / (size-1) * input_size (codec.py:237).
+#include <stdlib.h>
+
 #include "pp_common.h"
 
 namespace pp {
@@ -382,6 +384,334 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Screened path (the default when the convolved maps themselves are not requested): the result of the decode is
+// decided by a handful of pixels -- the arg-max of the convolved map and its four neighbours -- so the float64
+// convolution is evaluated ONLY there.
+//   1. the map goes HBM -> LDS once (f32, reflected halo), A = max |x| comes with it;
+//   2. the separable convolution runs over every pixel in float32 (row pass into a 4 B/pixel buffer, column pass
+//      on the fly), giving c32 with |c32 - c*| <= 41 u A of the reference value c* (u = 2^-24; the kernel is
+//      normalised, so every partial sum is bounded by A: (T + 1) u A per pass with T <= 19 taps, + u A for the
+//      reference's own rounding to float32);
+//   3. every pixel with c32 >= max(c32) - 128 u A is a candidate (contains every arg-max of c*: c* of a maximum is
+//      >= c*max, so its c32 >= c*max - 41 u A >= max(c32) - 82 u A);
+//   4. one wave per candidate evaluates c* exactly as the reference does -- row sums and the column sum as float64
+//      FMA chains over ascending taps, rounded to float32 once (bit-identical to decode_lds_kernel and, on every
+//      golden, to scipy) -- then the first-index arg-max over the candidates' exact values, the exact values of its
+//      four neighbours, and the float32 sub-pixel arithmetic of finalize().
+// LDS: 8 B per pixel (+ halo) instead of 12, 256 threads per map instead of 512: 5 workgroups per CU on 64x48 maps
+// (was 3), 2 on 96x72 (was 1).  Maps with non-finite values, or flat maps with more candidates than the list holds,
+// take the exact evaluation for every pixel that passes the predicate (slow, rare, still exact).
+// ---------------------------------------------------------------------------
+constexpr int DF_THREADS = 256;
+constexpr int DF_MAXCAND = 512;
+
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Float32 screening passes for a compile-time radius.  Row pass: 4 adjacent outputs per item from one aligned window
+// (two packed-f32 FMA chains); column pass: 4 vertically adjacent outputs per item.  The column-pass results stay in
+// registers (keep[][]), so the candidate test after the block-wide maximum needs no second pass.
+template <int R, int DF_KEEP>
+__device__ __forceinline__ void screen_passes(const float *__restrict__ rawp, int WP, float *__restrict__ tmp32, int H,
+                                              int W, const float (&w)[PP_MAX_TAPS], float (&keep)[DF_KEEP][4],
+                                              float &best_v) {
+  constexpr int T = 2 * R + 1, WIN = T + 3;
+  constexpr int CR = (R + 3) / 4, NCH = 2 * CR + 1, SKIP = 4 * CR - R;
+  const int tid = threadIdx.x;
+  const int W4 = (W + 3) >> 2;
+  for (int it = tid; it < H * W4; it += DF_THREADS) {
+    const int y = it / W4, x0 = (it - y * W4) * 4;
+    const float4 *rp = reinterpret_cast<const float4 *>(rawp + y * WP + x0 + DEC_HALO - 4 * CR);
+    float c[NCH * 4];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const float4 t = rp[q];
+      c[4 * q + 0] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
+    }
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const f32x2 wj = {w[j], w[j]};
+      a01 = __builtin_elementwise_fma(wj, (f32x2){c[SKIP + j], c[SKIP + j + 1]}, a01);
+      a23 = __builtin_elementwise_fma(wj, (f32x2){c[SKIP + j + 2], c[SKIP + j + 3]}, a23);
+    }
+    float *o = tmp32 + y * W + x0;
+    o[0] = a01.x;
+    if (x0 + 1 < W) o[1] = a01.y;
+    if (x0 + 2 < W) o[2] = a23.x;
+    if (x0 + 3 < W) o[3] = a23.y;
+  }
+  __syncthreads();
+  const int H4 = (H + 3) >> 2;
+#pragma unroll
+  for (int u = 0; u < DF_KEEP; ++u) {
+    const int it = tid + u * DF_THREADS;
+    keep[u][0] = keep[u][1] = keep[u][2] = keep[u][3] = -__builtin_inff();
+    if (it >= H4 * W) continue;
+    const int y4 = it / W, x = it - y4 * W, y0 = y4 * 4;
+    float v[WIN];
+    if (y0 >= R && y0 + 3 + R < H) {
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) v[j] = tmp32[(y0 - R + j) * W + x];
+    } else {
+#pragma unroll
+      for (int j = 0; j < WIN; ++j) v[j] = tmp32[reflect_idx(y0 - R + j, H) * W + x];
+    }
+    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const f32x2 wj = {w[j], w[j]};
+      a01 = __builtin_elementwise_fma(wj, (f32x2){v[j], v[j + 1]}, a01);
+      a23 = __builtin_elementwise_fma(wj, (f32x2){v[j + 2], v[j + 3]}, a23);
+    }
+    const float a[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (y0 + i >= H) continue;
+      keep[u][i] = a[i];
+      best_v = fmaxf(best_v, a[i]);
+    }
+  }
+}
+
+// exact value c*(y, x) by one wave: lanes 0..T-1 each run one row's float64 chain, lane 0 the column chain
+__device__ __forceinline__ float exact_conv_at(const float *__restrict__ rawp, int WP, int H, int W, int R,
+                                               const double *__restrict__ wk, int y, int x, double *__restrict__ scratch) {
+  const int lane = threadIdx.x & 63, T = 2 * R + 1;
+  if (lane < T) {
+    const int yy = reflect_idx(y - R + lane, H);
+    const float *rp = rawp + yy * WP + DEC_HALO + x - R;       // halo columns hold the reflected values (R <= 12)
+    double t = 0.0;
+    for (int j = 0; j < T; ++j) t = fma(wk[j], (double)rp[j], t);
+    scratch[lane] = t;
+  }
+  __builtin_amdgcn_wave_barrier();
+  double c = 0.0;
+  for (int i = 0; i < T; ++i) c = fma(wk[i], scratch[i], c);    // every lane computes it: uniform result
+  __builtin_amdgcn_wave_barrier();
+  return (float)c;
+}
+
+// DF_KEEP: column-pass items a thread keeps in registers (4 outputs each): 3 covers 64x48 maps (92 VGPRs: five
+// workgroups per CU, one round for the 1 088 maps of a bs-64 K=17 batch), 7 covers 96x72.
+template <int DF_KEEP>
+__global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_screen_kernel(
+    const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
+    int K, int H, int W, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y,
+    double in_w, double in_h, DecodeOut o) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = DF_THREADS / 64;
+  const int HW = H * W;
+  const int WP = 4 * ((W + 3) >> 2) + 2 * DEC_HALO;
+  float *rawp = reinterpret_cast<float *>(smem);                              // [H][WP]
+  float *tmp32 = rawp + (size_t)H * WP;                                       // [HW]
+  int *cand = reinterpret_cast<int *>(tmp32 + HW);                            // [DF_MAXCAND]
+  __shared__ double wk[PP_MAX_TAPS];
+  __shared__ double scratch[NW][PP_MAX_TAPS + 1];
+  __shared__ float redf[NW], redmin[NW], redmax[NW];
+  __shared__ Best red[NW];
+  __shared__ int ncand_s;
+  __shared__ float nbr[5];
+
+  const int map = blockIdx.x, k = map % K, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float *__restrict__ src = heatmaps + (size_t)map * HW;
+#ifdef PP_DSC_STAMPS
+  unsigned long long st[8];
+#define DSC(i_) st[i_] = __builtin_amdgcn_s_memtime()
+#else
+#define DSC(i_)
+#endif
+  DSC(0);
+  const int r = __builtin_amdgcn_readfirstlane(radius[k]);
+  if (tid < PP_MAX_TAPS) wk[tid] = taps[k * PP_MAX_TAPS + tid];
+  if (tid == 0) ncand_s = 0;
+  // 1. HBM -> LDS (+ reflected halo), A = max |x| (NaN / inf make A non-finite)
+  float amax = 0.f, vmin = __builtin_inff(), vmax = -__builtin_inff();
+  bool bad = false;
+  if ((W & 3) == 0) {
+    const int W4 = W >> 2;
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    for (int p = tid; p < H * W4; p += DF_THREADS) {
+      const int y = p / W4, xq = p - y * W4;
+      const float4 v = s4[p];
+      *reinterpret_cast<float4 *>(rawp + y * WP + DEC_HALO + 4 * xq) = v;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+      vmin = fminf(fminf(vmin, fminf(v.x, v.y)), fminf(v.z, v.w));
+      vmax = fmaxf(fmaxf(vmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
+    }
+  } else {
+    for (int p = tid; p < HW; p += DF_THREADS) {
+      const int y = p / W, x = p - y * W;
+      const float v = src[p];
+      rawp[y * WP + DEC_HALO + x] = v;
+      amax = fmaxf(amax, fabsf(v));
+      vmin = fminf(vmin, v);
+      vmax = fmaxf(vmax, v);
+      bad |= !(fabsf(v) <= 3.0e38f);
+    }
+  }
+  {
+    const int npad = WP - W;
+    const int q = tid & 31;
+    if (q < npad) {
+      const int col = q < DEC_HALO ? q : q + W;
+      const int sx = reflect_idx(col - DEC_HALO, W);
+      for (int y = tid >> 5; y < H; y += DF_THREADS / 32) rawp[y * WP + col] = src[y * W + sx];
+    }
+  }
+  amax = wave_max(amax);
+  vmax = wave_max(vmax);
+  vmin = -wave_max(-vmin);
+  const unsigned long long badm = __ballot(bad);
+  if (lane == 0) {
+    redf[wave] = badm ? __builtin_inff() : amax;
+    redmin[wave] = vmin;
+    redmax[wave] = vmax;
+  }
+  __syncthreads();
+  float A = redf[0], gmin = redmin[0], gmax = redmax[0];
+#pragma unroll
+  for (int w_ = 1; w_ < NW; ++w_) {
+    A = fmaxf(A, redf[w_]);
+    gmin = fminf(gmin, redmin[w_]);
+    gmax = fmaxf(gmax, redmax[w_]);
+  }
+  const bool finite = A <= 3.0e38f;
+  DSC(1);
+  if (finite && gmin == gmax) {
+    // constant map (e.g. an all-zero channel after the clamp): every pixel's float64 chain sees the same inputs, so
+    // every convolved value is the same number and np.argmax returns index 0 -- a border pixel, no sub-pixel step
+    if (tid == 0) {
+      auto at = [&](int, int) { return 0.f; };
+      finalize(map, B, K, H, W, 0, at, src, prob, vis, oks, err, den_x, den_y, in_w, in_h, o);
+    }
+    return;
+  }
+
+  // 2 + 3. float32 screening
+  float thr = -__builtin_inff();        // non-finite map: every pixel is a candidate
+  const int H4 = (H + 3) >> 2;
+  const bool keepable = H4 * W <= DF_KEEP * DF_THREADS;
+  bool listed = false;                  // candidates are in cand[0 .. ncand_s)
+  if (finite) {
+    float w32[PP_MAX_TAPS];
+#pragma unroll
+    for (int j = 0; j < PP_MAX_TAPS; ++j) w32[j] = (float)taps[k * PP_MAX_TAPS + j];
+    float best = -__builtin_inff();
+    float keep[DF_KEEP][4];
+#define PP_SCREEN(R_) screen_passes<R_, DF_KEEP>(rawp, WP, tmp32, H, W, w32, keep, best)
+    switch (r) {
+      case 2: PP_SCREEN(2); break;
+      case 3: PP_SCREEN(3); break;
+      case 4: PP_SCREEN(4); break;
+      case 5: PP_SCREEN(5); break;
+      case 6: PP_SCREEN(6); break;
+      case 7: PP_SCREEN(7); break;
+      case 8: PP_SCREEN(8); break;
+      default: PP_SCREEN(9); break;
+    }
+#undef PP_SCREEN
+    best = wave_max(best);
+    __syncthreads();                     // redf readers above are done
+    if (lane == 0) redf[wave] = best;
+    __syncthreads();
+    float m32 = redf[0];
+#pragma unroll
+    for (int w_ = 1; w_ < NW; ++w_) m32 = fmaxf(m32, redf[w_]);
+    thr = m32 - 128.0f * 5.9604645e-08f * A;
+    DSC(2);
+    if (keepable) {
+      listed = true;
+#pragma unroll
+      for (int u = 0; u < DF_KEEP; ++u) {
+        const int it = tid + u * DF_THREADS;
+        const int y4 = it / W, x = it - y4 * W;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (keep[u][i] >= thr) {       // rows beyond H and items beyond the map hold -inf
+            const int slot = atomicAdd(&ncand_s, 1);
+            if (slot < DF_MAXCAND) cand[slot] = (y4 * 4 + i) * W + x;
+          }
+      }
+    }
+  }
+  __syncthreads();
+  const int nc = (finite && listed) ? ncand_s : DF_MAXCAND + 1;
+  DSC(3);
+
+  // 4. exact values of the candidates, first-index arg-max (np.argmax semantics incl. NaN)
+  Best mine;
+  mine.v = -__builtin_inff();
+  mine.i = 0x7fffffff;
+  bool have = false;
+  auto consider = [&](int p) {
+    const float cv = exact_conv_at(rawp, WP, H, W, r, wk, p / W, p % W, scratch[wave]);
+    if (!have || better(cv, p, mine.v, mine.i)) {
+      mine.v = cv;
+      mine.i = p;
+      have = true;
+    }
+  };
+  if (nc <= DF_MAXCAND) {
+    for (int ci = wave; ci < nc; ci += NW) consider(cand[ci]);
+  } else if (finite) {
+    // more candidates than the list holds (flat map): every pixel whose float32 value passes the threshold.  The
+    // float32 column sum is re-evaluated per pixel by the whole wave redundantly (uniform), then the exact value.
+    for (int p = wave; p < HW; p += NW) {
+      const int y = p / W, x = p - y * W;
+      float a = 0.f;
+      for (int j = 0; j <= 2 * r; ++j) a = fmaf((float)wk[j], tmp32[reflect_idx(y - r + j, H) * W + x], a);
+      if (a >= thr) consider(p);
+    }
+  } else {
+    for (int p = wave; p < HW; p += NW) consider(p);
+  }
+  if (!have || lane != 0) {
+    // every lane of a wave holds the same (mine); keep one copy per wave for the reduction
+    if (lane != 0 || !have) {
+      mine.v = -__builtin_inff();
+      mine.i = 0x7fffffff;
+    }
+  }
+  DSC(4);
+  __syncthreads();
+  // block_argmax's better() treats a NaN value as winning; the "no candidate" sentinel (-inf, INT_MAX) never wins
+  const Best b = block_argmax(mine, red);
+  // exact neighbours of the winner (interior only), one wave each
+  const int bx = b.i % W, by = b.i / W;
+  const bool interior = bx > 0 && bx < W - 1 && by > 0 && by < H - 1;
+  if (interior) {
+    const int dyx[5][2] = {{0, 0}, {0, 1}, {0, -1}, {1, 0}, {-1, 0}};
+    for (int q = wave; q < 5; q += NW) {
+      const float cv = exact_conv_at(rawp, WP, H, W, r, wk, by + dyx[q][0], bx + dyx[q][1], scratch[wave]);
+      if (lane == 0) nbr[q] = cv;
+    }
+  }
+  __syncthreads();
+  DSC(5);
+  if (tid == 0) {
+    auto at = [&](int yy, int xx) {
+      return yy == by ? (xx == bx ? nbr[0] : (xx == bx + 1 ? nbr[1] : nbr[2])) : (yy == by + 1 ? nbr[3] : nbr[4]);
+    };
+    finalize(map, B, K, H, W, b.i, at, src, prob, vis, oks, err, den_x, den_y, in_w, in_h, o);
+  }
+#ifdef PP_DSC_STAMPS
+  DSC(6);
+  if (tid == 0) {
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(o.locs + (size_t)2 * B * K) + (size_t)map * 8;
+    d[0] = st[1] - st[0]; d[1] = st[2] - st[1]; d[2] = st[3] - st[2]; d[3] = st[4] - st[3]; d[4] = st[5] - st[4];
+    d[5] = st[6] - st[0]; d[6] = r; d[7] = nc;
+  }
+#endif
+#undef DSC
+}
+
+static size_t screen_lds_bytes(int H, int W) {
+  return ((size_t)H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) + (size_t)H * W + DF_MAXCAND) * 4;
+}
+
+// ---------------------------------------------------------------------------
 // Large-map path (map does not fit in LDS, e.g. the reference's own 256x256
 // test, tests/test_heatmap.py:6): three passes through a global workspace.
 // ---------------------------------------------------------------------------
@@ -449,6 +779,12 @@ static size_t lds_bytes(int H, int W) {
   return (size_t)H * W * 8 + (size_t)H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) * 4;
 }
 static bool fits_lds(int H, int W) { return lds_bytes(H, W) <= LDS_LIMIT; }
+// PP_DECODE_EXACT_ALL=1 forces the all-pixel float64 kernel (A/B runs and the equivalence test of the screened path)
+static bool getenv_flag(const char *name) {
+  const char *e = getenv(name);
+  return e && e[0] == '1';
+}
+static bool getenv_exact() { return getenv_flag("PP_DECODE_EXACT_ALL"); }
 
 }  // namespace pp
 
@@ -472,6 +808,32 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   hipStream_t s = (hipStream_t)stream;
   DecodeOut o{out_kpts, out_scores, out_locs, out_aux, out_err, out_packed};
   const int maps = B * K;
+#ifndef PP_DEC_STAMPS
+  constexpr size_t SCREEN_DYN_LIMIT = 156 * 1024;    // the kernel also holds ~1.5 KB of static LDS
+  // Measured (tools/decode_ab.py, one process, interleaved): 96x72 maps 699 vs 884 us per 128 x 133 maps (-21 %); 64x48
+  // maps 24.3 vs 22.9 us at B = 64 and 236 vs 234 us at B = 1024 (a tie: both forms are bound by the latency of their
+  // short barrier-separated phases, not by HBM, LDS or the FMA rate).  The screened form is the default where it
+  // wins (maps larger than 4096 pixels); PP_DECODE_SCREEN=1 forces it everywhere, PP_DECODE_EXACT_ALL=1 never.
+  const bool want_screen = getenv_flag("PP_DECODE_SCREEN") || (long long)H * W > 4096;
+  if (!out_conv && want_screen && !getenv_exact() && screen_lds_bytes(H, W) <= SCREEN_DYN_LIMIT) {
+    const size_t lds = screen_lds_bytes(H, W);
+    const int items = ((H + 3) / 4) * W;
+    if (items <= 3 * DF_THREADS) {
+      hipLaunchKernelGGL(decode_screen_kernel<3>, dim3(maps), dim3(DF_THREADS), lds, s, heatmaps, prob, vis, oks, err, B,
+                         K, H, W, taps, radius, den_x, den_y, in_w, in_h, o);
+    } else {
+      static thread_local unsigned long long attr_mask2 = 0;
+      int dev2 = 0;
+      if (lds > 48 * 1024 && attr_needed(attr_mask2, dev2))
+        PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_screen_kernel<7>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCREEN_DYN_LIMIT));
+      hipLaunchKernelGGL(decode_screen_kernel<7>, dim3(maps), dim3(DF_THREADS), lds, s, heatmaps, prob, vis, oks, err, B,
+                         K, H, W, taps, radius, den_x, den_y, in_w, in_h, o);
+    }
+    PP_CHECK_LAUNCH("decode_screen_kernel");
+    return 0;
+  }
+#endif
   if (fits_lds(H, W)) {
     const size_t lds = lds_bytes(H, W);
     static thread_local unsigned long long attr_mask = 0;

@@ -501,10 +501,11 @@ class HeadPlan:
                 else:
                     # few rows (16 B, then 4 B) against K = 9 C: split the taps over workgroups when the plain launch
                     # would leave most CUs idle behind 108 sequential K-tiles (S f32 partials, summed in the pooling)
-                    tiles = 4 * ((M + 191) // 192) * ((C + 191) // 192)
-                    split = 9 if tiles <= 40 else (3 if tiles <= 130 else 1)
-                    if not SPLITK_AUX:
-                        split = 1
+                    # The split is a property of the LAYER (3 for the first pooled stage, 9 from the second on), never
+                    # of the batch size: a crop's outputs stay bit-identical whatever batch it is computed in (the
+                    # partial-sum order would otherwise change with B).  At large batches the partials cost ~0.2 % of
+                    # the step.
+                    split = (3 if i == 1 else 9) if SPLITK_AUX else 1
                     if split == 1:
                         ops.gemm(a, self.aux_w[i], conv, M=M, N=C, Kd=9 * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
                                  bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,

@@ -222,3 +222,46 @@ def test_encode_batched_equals_per_crop_oracle(pp):
         ref = orc.probmap_encode(kps[i], viss[i], (192, 256), (48, 64), orc.COCO17_SIGMAS, None)
         assert np.array_equal(heat[i], ref["heatmaps"]) and np.array_equal(wts[i:i + 1], ref["keypoint_weights"])
     assert pm.encode_device(np.zeros((0, 17, 2), np.float32))[0].shape == (0, 17, 64, 48)
+
+
+def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
+    """The default decode evaluates the float64 convolution only at the float32-screened candidates
+    (decode_screen_kernel); PP_DECODE_EXACT_ALL=1 selects the all-pixel float64 kernel.  Both must return identical
+    numbers on random, peaked, flat, saturated, tied, negative, non-finite and tiny maps."""
+    import torch
+    rng = np.random.default_rng(77)
+    cases = []
+    cases.append(orc.synthetic_heatmaps(6, 17, 64, 48, seed=5, kind="peaked"))
+    cases.append(orc.synthetic_heatmaps(3, 17, 64, 48, seed=6, kind="uniform"))
+    cases.append(orc.synthetic_heatmaps(2, 133, 96, 72, seed=7, kind="peaked"))
+    sat = np.zeros((2, 17, 64, 48), np.float32)
+    sat[:, :, 10:50, 5:40] = 1.0                                        # clamped plateau: hundreds of exact ties
+    sat[1, 3] = 0.25                                                     # constant map
+    sat[1, 4] = 0.0
+    sat[1, 5, 0, 0] = 1.0                                                # corner peak
+    sat[1, 6, 63, 47] = 1.0
+    sat[1, 7] = rng.random((64, 48), dtype=np.float32) * 1e-6            # tiny values: threshold scales with max |x|
+    sat[1, 8] = -rng.random((64, 48), dtype=np.float32)                  # negative map
+    sat[1, 9, 20, 20] = np.nan
+    sat[1, 10, 5, 5] = np.inf
+    sat[1, 11] = np.round(rng.random((64, 48), dtype=np.float32) * 3) / 3   # many exact ties at several levels
+    cases.append(sat)
+    cases.append(rng.random((2, 5, 7, 5), dtype=np.float32))            # smaller than the kernel radius
+    cases.append(rng.random((1, 3, 33, 27), dtype=np.float32))          # W % 4 != 0
+    for hm in cases:
+        B, K, H, W = hm.shape
+        sig = (orc.COCO17_SIGMAS if K == 17 else np.random.default_rng(K).uniform(0.02, 0.11, K))
+        codec = pp.Codec(pp.ProbMap((4 * W, 4 * H), (W, H), sig))
+        aux = [rng.random((B, K, 1, 1), dtype=np.float32) for _ in range(4)]
+        pred = tuple(torch.from_numpy(a).cuda() for a in (hm, *aux))
+        monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
+        monkeypatch.setenv("PP_DECODE_SCREEN", "1")          # the screened form on every map size
+        fast = codec.decode(pred)
+        monkeypatch.delenv("PP_DECODE_SCREEN", raising=False)
+        monkeypatch.setenv("PP_DECODE_EXACT_ALL", "1")
+        slow = codec.decode(pred)
+        monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
+        np.testing.assert_array_equal(fast[0][0], slow[0][0])
+        np.testing.assert_array_equal(fast[0][1], slow[0][1])
+        for a, b in zip(fast[1:], slow[1:]):
+            np.testing.assert_array_equal(a, b)
