@@ -1556,6 +1556,258 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// "Duo" form: 192x192 tile, FOUR waves (2 x 2, 96x96 per wave), K-tiles of 32 (64-byte rows), 3 LDS stages of
+// 24 KB = 72 KB per workgroup, <= 256 VGPRs: TWO workgroups are resident per CU (one wave of each per SIMD).
+//
+// Why: the per-launch timeline (tools/gemm_timeline.py) shows a workgroup of the 8-wave form spending 35-50 % of its
+// life outside the K-loop -- pipeline fill, the residual / bias fetch, and an epilogue in which all 256 CUs store in
+// the same phase -- while nothing else can run on its CU (144 KB of LDS).  Two half-size workgroups per CU drift out
+// of phase on their own: one's fill / epilogue runs under the other's K-loop, and inside the K-loop one's DMA issue
+// and LDS reads run under the other's MFMAs.  96x96 wave tiles also read a third less LDS per flop than 96x48.
+// Plain layers only (no gather / row map / LayerNorm modes / fp8); epilogue straight from the accumulators
+// (8-byte bf16 or 16-byte fp32 stores per lane: no LDS staging to wait for, its inefficiency hides under the
+// neighbour workgroup).  Swizzle for 64-byte rows: physical 16-B chunk = logical ^ perm[(row >> 2) & 3],
+// perm = {0, 3, 2, 1}: every 16-lane group of a ds_read_b128 (rows r .. r+15, chunk = lane >> 4) covers all 16
+// bank slots of the 256-byte LDS row.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PP_GEMM_TIMELINE
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+  unsigned long long rt_loop0 = 0, rt_loop1 = 0;
+#endif
+#ifndef PP_DUO_DELAY
+#define PP_DUO_DELAY 0       /* units of s_sleep(127) ~ 3.9 us; measured: 0 best (fc1 87.2 / 90.9 / 101 us at 0 / 2 / 4) */
+#endif
+  // Optional start stagger of the second slot of every CU (block ids b and b + 256 share a CU on a >= 512-workgroup
+  // launch; speed only, never correctness).  Tried because two workgroups that start together run the same phases at
+  // the same time; measured a loss at every delay, so it is off.
+  if (PP_DUO_DELAY > 0 && gridDim.x >= 512 && ((blockIdx.x >> 8) & 1)) {
+    for (int d = 0; d < PP_DUO_DELAY; ++d) __builtin_amdgcn_s_sleep(127);
+  }
+  constexpr int BM = 192, BN = 192, STAGES = 3, BK = 32, RB = 64;          // RB: bytes of K per staged row
+  constexpr int PA = 3, PB = 3, PIECES = PA + PB, TM = 6, TN = 6;           // 1-KiB pieces (16 rows) per wave per K-tile
+  constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int epi = p.epilogue;
+
+  int tm, tn;
+  if (p.blocked) {
+    constexpr int RM = 8;
+    const int RN = p.rn, RT = RM * RN;
+    const int nbm = (p.tiles_m + RM - 1) / RM, nbn = (p.tiles_n + RN - 1) / RN;
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int g = (j / RT) * 8 + x, idx = j % RT;
+    if (g >= nbm * nbn) return;
+    const int bmi = g / nbn, bni = g - bmi * nbn;
+    tm = bmi * RM + idx / RN;
+    tn = bni * RN + idx % RN;
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+  } else {
+    tm = blockIdx.x / p.tiles_n;
+    tn = blockIdx.x - tm * p.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = p.Kd / BK;
+
+  // ---- staging: lane -> (row in piece = lane >> 2, physical chunk = lane & 3); logical chunk = physical ^ perm
+  const int prow = lane >> 2, pchunk = lane & 3;
+  const int perm_p = (0x1230 >> (4 * ((prow >> 2) & 3))) & 3;      // {0, 3, 2, 1}[(row >> 2) & 3]
+  const int lchunk_off = (pchunk ^ perm_p) * 16;
+  const char *zero_line = (const char *)g_zero_page + (((blockIdx.x * 29 + wave) * 16 + prow) & 63) * 128 + pchunk * 16;
+  const char *a_src[PA];
+  const char *w_src[PB];
+  bool w_ok[PB];
+#pragma unroll
+  for (int j = 0; j < PA; ++j) {
+    const int r = (wave * PA + j) * 16 + prow;
+    a_src[j] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda * 2 + lchunk_off;
+  }
+#pragma unroll
+  for (int j = 0; j < PB; ++j) {
+    const int r = n0 + (wave * PB + j) * 16 + prow;
+    w_ok[j] = r < p.N;
+    w_src[j] = w_ok[j] ? p.W + (size_t)r * p.ldw * 2 + lchunk_off : zero_line;
+  }
+  const unsigned lds0 = lds_offset_of(smem);
+  unsigned st_ldsA = 0, st_ldsB = 0;
+  size_t st_koff = 0;
+  auto stage_begin = [&](int kt, int buf) __attribute__((always_inline)) {
+    st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
+    st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + wave * PB * 1024);
+    st_koff = (size_t)kt * RB;
+  };
+  auto stage_piece = [&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if constexpr (q < PA) {
+      glds16(a_src[q] + st_koff, st_ldsA + q * 1024);
+    } else {
+      constexpr int j = q - PA;
+      glds16(w_ok[j] ? w_src[j] + st_koff : w_src[j], st_ldsB + j * 1024);
+    }
+  };
+  auto stage_all = [&](int kt, int buf) __attribute__((always_inline)) {
+    stage_begin(kt, buf);
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      (stage_piece(std::integral_constant<int, Q>{}), ...);
+    }(std::make_integer_sequence<int, PIECES>{});
+  };
+
+  f32x4 acc[TM][TN];
+  // fragment offsets: row (w? * 96 + 16 i + frow), chunk fq ^ perm[(frow >> 2) & 3] (i only adds multiples of 16 rows)
+  const int perm_f = (0x1230 >> (4 * ((frow >> 2) & 3))) & 3;
+  const unsigned offA = (wm * 96 + frow) * RB + ((fq ^ perm_f) << 4);
+  const unsigned offB = A_BYTES + (wn * 96 + frow) * RB + ((fq ^ perm_f) << 4);
+  auto compute = [&](int buf, auto do_stage_c) __attribute__((always_inline)) {
+    constexpr bool DO_STAGE = decltype(do_stage_c)::value;
+    const char *sb = smem + buf * STAGE_BYTES;
+    uint4 bf[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const uint4 *>(sb + offB + j * 16 * RB);
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+      ([&] {
+        constexpr int i = I;
+        const uint4 af = *reinterpret_cast<const uint4 *>(sb + offA + i * 16 * RB);
+        if constexpr (DO_STAGE) {
+          __builtin_amdgcn_sched_barrier(0);
+          stage_piece(std::integral_constant<int, i>{});        // PIECES == TM: one piece per MFMA group
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8 *>(&bf[j]),
+                                                              *reinterpret_cast<const bf16x8 *>(&af), acc[i][j], 0, 0, 0);
+      }(), ...);
+    }(std::make_integer_sequence<int, TM>{});
+  };
+  static_assert(PIECES == TM, "one DMA piece per MFMA group");
+
+  // ---- pipeline fill, then the additive epilogue terms straight into the accumulators (residual / row bias)
+#pragma unroll
+  for (int s_ = 0; s_ < STAGES - 1; ++s_)
+    if (s_ < nkt) stage_all(s_, s_);
+  const float *Rb = p.residual;
+  const float *init_base = (epi & PP_EPI_RESIDUAL) ? Rb : ((epi & PP_EPI_ROWBIAS) ? p.rowbias : nullptr);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * 96 + i * 16 + frow;
+    const size_t rowbase = (epi & PP_EPI_RESIDUAL) ? (size_t)m * p.ldc
+                                                   : (size_t)(m % (p.rowbias_period > 0 ? p.rowbias_period : 1)) * p.ldc;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * 96 + j * 16 + fq * 4;
+      f32x4 c = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (init_base && m < p.M && n < p.N) {
+        const float4 t = *reinterpret_cast<const float4 *>(init_base + rowbase + n);
+        c = f32x4{t.x, t.y, t.z, t.w};
+      }
+      acc[i][j] = c;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);     // retire them with a wait hipcc models (see gemm_kernel): no vmcnt(0) in the loop
+#ifdef PP_GEMM_TIMELINE
+  rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  int buf = 0, kt = 0;
+  for (; kt + STAGES - 1 < nkt; ++kt) {
+    wait_vmcnt<(STAGES - 2) * PIECES>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int nb = buf + STAGES - 1;
+    if (nb >= STAGES) nb -= STAGES;
+    stage_begin(kt + STAGES - 1, nb);
+    compute(buf, std::true_type{});
+    if (++buf == STAGES) buf = 0;
+  }
+  for (; kt < nkt; ++kt) {
+    if (kt + STAGES - 1 <= nkt) {
+      wait_vmcnt<(STAGES - 2) * PIECES>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(buf, std::false_type{});
+    if (++buf == STAGES) buf = 0;
+  }
+
+#ifdef PP_GEMM_TIMELINE
+  rt_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- epilogue: the tile goes through the (now idle) LDS ring in column passes and leaves as whole rows (16 B per
+  // lane, contiguous per row); lane (frow, fq) of a wave owns row m and 4 consecutive columns of every 16-wide tile.
+  const bool out_f32 = (epi & PP_EPI_OUT_F32) != 0;
+  auto staged = [&]<int OES>(std::integral_constant<int, OES>) __attribute__((always_inline)) {
+    constexpr int NPASS = OES == 2 ? 2 : 4;          // 96 bf16 or 48 f32 columns per pass: 192 x 208 B = 39 KB
+    constexpr int PBN = BN / NPASS, CS = PBN * OES + 16, CPR = PBN * OES / 16;
+    constexpr int JPP = PBN / 16;                    // 16-wide tiles of one wave per pass (6 or 3)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      __syncthreads();
+      const int wn_of_pass = pass * PBN / 96;        // which wave column owns this pass
+      if (wn == wn_of_pass) {
+        const int j0 = (pass * PBN - wn_of_pass * 96) / 16;
+#pragma unroll
+        for (int jj = 0; jj < JPP; ++jj) {
+          const int j = j0 + jj;
+          const int n = n0 + wn * 96 + j * 16 + fq * 4;
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((epi & PP_EPI_BIAS) && n < p.N) b4 = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            // the accumulator index must be a compile-time constant: select by unrolled comparison
+            f32x4 c = acc[i][0];
+#pragma unroll
+            for (int q = 1; q < TN; ++q) c = (j == q) ? acc[i][q] : c;
+            float v[4] = {c[0] + b4.x, c[1] + b4.y, c[2] + b4.z, c[3] + b4.w};
+            if (epi & PP_EPI_GELU) gelu4<bf16_t>(v);
+            if (epi & PP_EPI_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            char *dst = smem + (wm * 96 + i * 16 + frow) * CS + (jj * 16 + fq * 4) * OES;
+            if constexpr (OES == 4) {
+              *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              uint2 pk;
+              pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+              pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              *reinterpret_cast<uint2 *>(dst) = pk;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int ncols16 = max(0, min(CPR, (p.N - n0 - pass * PBN) * OES / 16));
+      for (int c = tid; c < BM * CPR; c += 256) {
+        const int lr = c / CPR, cc = c - lr * CPR;
+        if (m0 + lr >= p.M || cc >= ncols16) continue;
+        const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
+        *reinterpret_cast<uint4 *>(p.C + ((size_t)(m0 + lr) * p.ldc + n0 + pass * PBN) * OES + cc * 16) = v;
+      }
+    }
+  };
+  if (out_f32) staged(std::integral_constant<int, 4>{});
+  else staged(std::integral_constant<int, 2>{});
+#ifdef PP_GEMM_TIMELINE
+  if ((p.epilogue & (1 << 30)) && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
+                            ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = rt_entry; o[1] = rt_loop0; o[2] = rt_loop1; o[3] = rt_end;
+    o[4] = __builtin_amdgcn_s_getreg(63492);
+    o[5] = __builtin_amdgcn_s_getreg(63508);
+    o[6] = 1; o[7] = (unsigned long long)tm << 32 | (unsigned)tn;
+  }
+#endif
+}
+
 }  // namespace pp
 
 #ifndef PP_CFG5_VS_CFG3
@@ -1648,7 +1900,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
   // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 13, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 14, "pp_gemm: bad tile selector %d", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -1672,7 +1924,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12 || cfg == 13) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12 || cfg == 13 || cfg == 14) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   dim3 grid;
@@ -1698,6 +1950,25 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_REQUIRE(a->stats_parts == p.tiles_n, "pp_gemm: stats_parts=%d but this launch has %d column tiles",
                a->stats_parts, p.tiles_n);
   hipStream_t s = (hipStream_t)stream;
+  if (cfg == 14) {
+    // duo form (gemm_duo_kernel): plain bf16 layers, K a multiple of 32
+    PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && batch == 1 && a->Kd % 32 == 0 &&
+                   !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | PP_EPI_RESIDUAL | PP_EPI_OUT_F32 |
+                                     PP_EPI_ROWBIAS | (1 << 30))) &&
+                   (!(a->epilogue & (PP_EPI_RESIDUAL | PP_EPI_ROWBIAS)) || (a->epilogue & PP_EPI_OUT_F32)) &&
+                   p.lds_epilogue,
+               "pp_gemm: tile 14 (two workgroups per CU) serves plain bf16 GEMMs (bias / GELU / ReLU / f32 residual) whose "
+               "output rows are whole 16-byte chunks (N, ldc multiples of 8 for bf16 / 4 for f32 outputs, C 16-byte aligned)");
+    constexpr int lds = 3 * (192 + 192) * 64;
+    static thread_local unsigned long long attr_mask = 0;
+    int dev_ = 0;
+    if (attr_needed(attr_mask, dev_))
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_duo_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(gemm_duo_kernel, grid, dim3(256), lds, s, p);
+    PP_CHECK_LAUNCH("gemm_duo_kernel");
+    return 0;
+  }
   if (cfg == 13) {
     // persistent 192x192 form (gemm_persist_kernel): plain bf16 -> bf16 layers only
     PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && p.lds_epilogue && batch == 1 &&

@@ -49,6 +49,31 @@ def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
     torch.testing.assert_close(out.double(), ref, **_tol(dtype, dtype))
 
 
+@pytest.mark.parametrize("tile", [13, 14])
+@pytest.mark.parametrize("M,N,K,epi", [(384, 768, 768, "gelu"), (1536, 2304, 768, "none"), (200, 264, 96, "relu"),
+                                       (2000, 388, 1024, "resid")])
+def test_gemm_experimental_forms_tile13_tile14(ops, tile, M, N, K, epi):
+    """The persistent stream (13) and the two-workgroups-per-CU form (14): bf16 plain layers, checked like any tile."""
+    dtype = torch.bfloat16
+    if K % 64 and tile == 13:
+        pytest.skip("tile 13 stages 64-deep K-tiles")
+    A, W = _rand((M, K), dtype, 1), _rand((N, K), dtype, 2, K ** -0.5)
+    b = _rand((N,), torch.float32, 3)
+    pre = A.double() @ W.double().t() + b.double()
+    if epi == "resid":
+        if tile == 13:
+            pytest.skip("tile 13 writes bf16 outputs only")
+        res = _rand((M, N), torch.float32, 4)
+        want = res.double() + pre
+        ops.linear(A, W, b, out=res, residual=res, tile=tile)
+        torch.testing.assert_close(res.double(), want, **_tol(dtype, torch.float32))
+        return
+    flag = {"gelu": ops.EPI_GELU, "relu": ops.EPI_RELU, "none": 0}[epi]
+    out = ops.linear(A, W, b, epilogue=flag, tile=tile)
+    ref = {"gelu": F.gelu, "relu": F.relu, "none": lambda t: t}[epi](pre)
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype, dtype))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 384, 256, 256
