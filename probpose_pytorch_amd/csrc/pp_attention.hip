@@ -51,6 +51,7 @@ template <int HD> struct AttGeom {
   }
 };
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float att_f32x2 __attribute__((ext_vector_type(2)));
 
 // Diagnostic build only (-DPP_ATT_STAMPS): phase cycle counts of wave 0 go behind the output tensor.
 #ifdef PP_ATT_STAMPS
@@ -69,6 +70,9 @@ __device__ __forceinline__ unsigned long long att_stamp() {
 __device__ __attribute__((aligned(256))) unsigned char g_att_zero[1024];
 
 __device__ __forceinline__ void att_glds16(const void *gsrc, unsigned lds_off_uniform) {
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 1
+  return;   // ablation (tools/att_ablate.sh): no K / V traffic
+#endif
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -88,11 +92,32 @@ __device__ __forceinline__ unsigned att_pack_fp8x4(float a, float b, float c, fl
   return (unsigned)w;
 }
 
+// two floats -> packed bf16 pair in ONE instruction (round-to-nearest-even, as f32_to_bf16)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
 
-template <int AT_HD>
+// 16-byte global load the compiler's vmcnt bookkeeping does not see (the pipelined staging below counts its own waits)
+__device__ __forceinline__ uint4 att_gload16(const void *gsrc) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(gsrc) : "memory");
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <int PENDING>
+__device__ __forceinline__ void att_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");
+}
+
+// PIPE: the staging is issued as Q, then groups of 12 one-KiB pieces (3 per wave) in the order the products consume them
+// (hd 64: K block 0, V block 0, K block 1, V block 1; hd 32: K+V block 0, K+V block 1), and every product waits only
+// for its own group (counted vmcnt + barrier).  Only Q and the first group are requested up front; the other groups
+// are requested from inside the first product, because a wave sits in the issue of a load for as long as the memory
+// pipeline is backed up.  PIPE = false is the round-1 form (one vmcnt(0) + barrier after all loads), kept for A/B
+// (PP_ATT_PIPE=0).
+template <int AT_HD, bool PIPE>
 __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__restrict__ qkv,
                                                                 bf16_t *__restrict__ out, int N,
                                                                 int heads, float scale_log2e, float fp8_inv_scale) {
@@ -108,12 +133,45 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
   const int lrow = lane & 15, g = lane >> 4;
 
   ATT_STAMP(t0);
+  const int q0 = wave * (AT_QT * 16);
+  uint4 qf[AT_QT][G::KS];
+  constexpr int NG = (AT_HD == 64) ? 4 : 2;            // PIPE: DMA groups, 3 pieces per wave each
+  constexpr int NLATE = 3 * (NG - 1);                  // pieces per wave issued inside the first product
+  // K and V go into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), both row-major; the 16-B chunk XOR
+  // swizzle is applied on the per-lane SOURCE address so the LDS image stays lane-linear.  V is NOT transposed here:
+  // the second product reads it through ds_read_b64_tr_b16.  Piece j of group gi for this wave:
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+  auto issue_piece = [&](int gi, int j) __attribute__((always_inline)) {
+    constexpr int PPB = 96 / G::RPP;                    // pieces per key block per matrix: 12 (hd 64) or 6 (hd 32)
+    const int prow = lane / G::CHUNKS, pchunk = lane % G::CHUNKS;
+    const int p = wave * 3 + j;                         // piece of the group, 0..11
+    const int mat = (AT_HD == 64) ? (gi & 1) : p / PPB;                        // 0 = K, 1 = V
+    const int piece = (AT_HD == 64) ? (gi >> 1) * PPB + p : gi * PPB + p % PPB;     // 1-KiB piece of that matrix
+    const int r = piece * G::RPP + prow;
+    const int lchunk = G::swz(r, pchunk);
+    const void *src = (r < N) ? (const void *)(base + (size_t)r * ld + (1 + mat) * C + lchunk * 8)
+                              : (const void *)(g_att_zero + lane * 16);
+    att_glds16(src, __builtin_amdgcn_readfirstlane(lds0 + mat * (AT_NMAX * AT_KROW) + piece * 1024));
+  };
+  if constexpr (PIPE) {
+    // ---- Q fragments first (B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]), by loads the compiler
+    // does not count; rows >= N read the zero line
+#pragma unroll
+    for (int t = 0; t < AT_QT; ++t) {
+      const int q = q0 + t * 16 + lrow;
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s)
+        qf[t][s] = att_gload16(q < N ? (const void *)(base + (size_t)q * ld + s * 32 + g * 8)
+                                     : (const void *)(g_att_zero + lane * 16));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue_piece(0, j);      // group 0 now; the others are issued inside the first product
+  } else {
   // ---- stage K and V into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 24 one-KiB
   // pieces per wave issued back to back, one wait), both row-major; the 16-B chunk XOR swizzle is
   // applied on the per-lane SOURCE address so the LDS image stays lane-linear.  Rows >= N read a
   // zero line.  V is NOT transposed here: the second product reads it through ds_read_b64_tr_b16.
   {
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
     constexpr int PIECES_W = AT_NMAX / G::RPP / 4;       // 1-KiB pieces per wave, for K and for V
     const int prow = lane / G::CHUNKS, pchunk = lane % G::CHUNKS;
 #pragma unroll
@@ -128,8 +186,6 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
   }
 
   // ---- Q fragments straight from global: B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]
-  const int q0 = wave * (AT_QT * 16);
-  uint4 qf[AT_QT][G::KS];
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
     const int q = q0 + t * 16 + lrow;
@@ -139,9 +195,19 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       if (q < N) qf[t][s] = *reinterpret_cast<const uint4 *>(base + (size_t)q * ld + s * 32 + g * 8);
     }
   }
+  }
   ATT_STAMP(t1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (and the Q loads) have landed
-  __syncthreads();
+  if constexpr (PIPE) {
+    att_wait_barrier<0>();                             // Q and the first group have landed, for every wave
+#pragma unroll
+    for (int t = 0; t < AT_QT; ++t)
+#pragma unroll
+      for (int s = 0; s < G::KS; ++s)     // uses of Q stay below the wait
+        asm volatile("" : "+v"(qf[t][s].x), "+v"(qf[t][s].y), "+v"(qf[t][s].z), "+v"(qf[t][s].w));
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (and the Q loads) have landed
+    __syncthreads();
+  }
   ATT_STAMP(t2);
 
   // ---- two key blocks of 96 keys, flash style: only 6 x QT score tiles (72 registers) are live at a
@@ -158,8 +224,14 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) oacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 3
+  if (N < 0)   // ablation: loads and stores only
+#endif
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
+    if constexpr (PIPE) {
+      if (kb == 1) att_wait_barrier<(AT_HD == 64) ? 3 : 0>();      // K (hd 32: K and V) of block 1
+    }
     // S^T block = K_block Q^T : sacc[kt][t] rows = keys 96*kb + 16*kt + 4g + r, col = query
     f32x4 sacc[KB_TILES][AT_QT];
 #pragma unroll
@@ -180,6 +252,14 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
                                                                 *reinterpret_cast<const bf16x8 *>(&qf[t][s]),
                                                                 sacc[kt][t], 0, 0, 0);
       }
+      if constexpr (PIPE) {
+        // the rest of K / V is requested here, spread over the first product, so that no wave sits in the (memory-
+        // throttled) issue of all 18 loads before it computes
+        if (kb == 0) {
+#pragma unroll
+          for (int i = kt * NLATE / KB_TILES; i < (kt + 1) * NLATE / KB_TILES; ++i) issue_piece(1 + i / 3, i % 3);
+        }
+      }
     }
     // online softmax over this block's keys, per query column.  VALU diet (this phase, not the MFMAs,
     // bounds the kernel): padded keys are masked through the accumulator init (below), scores are
@@ -195,15 +275,33 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
       const float m_new = fmaxf(m_run[t], mb * scale_log2e);   // running max of the SCALED scores; finite
       const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);  // block 0: exp2(-inf) = 0
-      float l = 0.f;
+      // two scores per instruction: v_pk_fma_f32 for the exponent, v_pk_add_f32 for the partial sums
+      att_f32x2 l2 = {0.f, 0.f};
+      const att_f32x2 c2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
 #pragma unroll
       for (int kt = 0; kt < KB_TILES; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], scale_log2e, -m_new));
-          sacc[kt][t][r] = pv;
-          l += pv;
+        for (int r = 0; r < 4; r += 2) {
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 4
+          const att_f32x2 e = {fmaf(sacc[kt][t][r], scale_log2e, -m_new), fmaf(sacc[kt][t][r + 1], scale_log2e, -m_new)};
+#else
+          const att_f32x2 e = __builtin_elementwise_fma((att_f32x2){sacc[kt][t][r], sacc[kt][t][r + 1]}, c2, nm2);
+#endif
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 2
+          const att_f32x2 pv = e;   // ablation: no exponentials
+#else
+          const att_f32x2 pv = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+#endif
+          sacc[kt][t][r] = pv.x;
+          sacc[kt][t][r + 1] = pv.y;
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 4
+          l2.x += pv.x;
+          l2.x += pv.y;
+#else
+          l2 += pv;
+#endif
         }
+      const float l = l2.x + l2.y;
       l_run[t] = l_run[t] * alpha + l;
       m_run[t] = m_new;
 #pragma unroll
@@ -212,6 +310,9 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       }
     }
     // O^T += V_block^T P_block^T : rows = dims 16*dt + 4g + r, col = query
+    if constexpr (PIPE && AT_HD == 64) {
+      if (kb == 0) att_wait_barrier<6>(); else att_wait_barrier<0>();   // V of this block
+    }
 #pragma unroll
     for (int u = 0; u < KB_TILES / 2; ++u) {  // 32 keys per step
       uint4 pf[AT_QT];
@@ -400,15 +501,33 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
       mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
       const float m_new = fmaxf(m_run[t], mb * scale_log2e);
       const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
-      float l = 0.f;
+      // two scores per instruction: v_pk_fma_f32 for the exponent, v_pk_add_f32 for the partial sums
+      att_f32x2 l2 = {0.f, 0.f};
+      const att_f32x2 c2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
 #pragma unroll
       for (int kt = 0; kt < KB_TILES; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kt][t][r], scale_log2e, -m_new));
-          sacc[kt][t][r] = pv;
-          l += pv;
+        for (int r = 0; r < 4; r += 2) {
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 4
+          const att_f32x2 e = {fmaf(sacc[kt][t][r], scale_log2e, -m_new), fmaf(sacc[kt][t][r + 1], scale_log2e, -m_new)};
+#else
+          const att_f32x2 e = __builtin_elementwise_fma((att_f32x2){sacc[kt][t][r], sacc[kt][t][r + 1]}, c2, nm2);
+#endif
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 2
+          const att_f32x2 pv = e;   // ablation: no exponentials
+#else
+          const att_f32x2 pv = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+#endif
+          sacc[kt][t][r] = pv.x;
+          sacc[kt][t][r + 1] = pv.y;
+#if defined(PP_ATT_ABL) && PP_ATT_ABL == 4
+          l2.x += pv.x;
+          l2.x += pv.y;
+#else
+          l2 += pv;
+#endif
         }
+      const float l = l2.x + l2.y;
       l_run[t] = l_run[t] * alpha + l;
       m_run[t] = m_new;
 #pragma unroll
@@ -502,12 +621,18 @@ static int attention_dispatch(const void *qkv, void *out, int B, int N, int head
   if (dtype == PP_BF16) {
     if ((hd == 64 || hd == 32) && N <= AT_NMAX && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0) {
       const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
-      if (hd == 64)
-        hipLaunchKernelGGL(attention_mfma_kernel<64>, dim3(B * heads), dim3(256), AttGeom<64>::LDS, s,
-                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e, fp8_inv_scale);
+      static const bool pipe = []() { const char *e = getenv("PP_ATT_PIPE"); return !(e && e[0] == '0'); }();
+      const dim3 grid(B * heads), block(256);
+      const bf16_t *qp = (const bf16_t *)qkv;
+      bf16_t *op = (bf16_t *)out;
+      if (hd == 64 && pipe)
+        hipLaunchKernelGGL((attention_mfma_kernel<64, true>), grid, block, AttGeom<64>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
+      else if (hd == 64)
+        hipLaunchKernelGGL((attention_mfma_kernel<64, false>), grid, block, AttGeom<64>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
+      else if (pipe)
+        hipLaunchKernelGGL((attention_mfma_kernel<32, true>), grid, block, AttGeom<32>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
       else
-        hipLaunchKernelGGL(attention_mfma_kernel<32>, dim3(B * heads), dim3(256), AttGeom<32>::LDS, s,
-                           (const bf16_t *)qkv, (bf16_t *)out, N, heads, scale_log2e, fp8_inv_scale);
+        hipLaunchKernelGGL((attention_mfma_kernel<32, false>), grid, block, AttGeom<32>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
       PP_CHECK_LAUNCH("attention_mfma_kernel");
       return 0;
     }
