@@ -99,25 +99,19 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return r;
 }
 
-// 16-byte global load the compiler's vmcnt bookkeeping does not see (the pipelined staging below counts its own waits)
-__device__ __forceinline__ uint4 att_gload16(const void *gsrc) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(gsrc) : "memory");
-  return make_uint4(v.x, v.y, v.z, v.w);
-}
 template <int PENDING>
 __device__ __forceinline__ void att_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");
 }
 
-// PIPE: the staging is issued as Q, then groups of 12 one-KiB pieces (3 per wave) in the order the products consume them
+// The staging is issued as Q, then groups of 12 one-KiB pieces (3 per wave) in the order the products consume them
 // (hd 64: K block 0, V block 0, K block 1, V block 1; hd 32: K+V block 0, K+V block 1), and every product waits only
 // for its own group (counted vmcnt + barrier).  Only Q and the first group are requested up front; the other groups
 // are requested from inside the first product, because a wave sits in the issue of a load for as long as the memory
-// pipeline is backed up.  PIPE = false is the round-1 form (one vmcnt(0) + barrier after all loads), kept for A/B
-// (PP_ATT_PIPE=0).
-template <int AT_HD, bool PIPE>
+// pipeline is backed up.  (The round-1 form -- everything requested up front, one vmcnt(0) + barrier -- measured
+// 23.7 us against 23.2 us for ViT-B bs 64 and 19.4 against 16.7 us for hd 32 in one process.)
+// FULL: N == 192 exactly (every 256x192 model): no key masks and no row guards.
+template <int AT_HD, bool FULL>
 __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__restrict__ qkv,
                                                                 bf16_t *__restrict__ out, int N,
                                                                 int heads, float scale_log2e, float fp8_inv_scale) {
@@ -135,7 +129,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
   ATT_STAMP(t0);
   const int q0 = wave * (AT_QT * 16);
   uint4 qf[AT_QT][G::KS];
-  constexpr int NG = (AT_HD == 64) ? 4 : 2;            // PIPE: DMA groups, 3 pieces per wave each
+  constexpr int NG = (AT_HD == 64) ? 4 : 2;            // DMA groups, 3 pieces per wave each
   constexpr int NLATE = 3 * (NG - 1);                  // pieces per wave issued inside the first product
   // K and V go into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip), both row-major; the 16-B chunk XOR
   // swizzle is applied on the per-lane SOURCE address so the LDS image stays lane-linear.  V is NOT transposed here:
@@ -149,65 +143,28 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
     const int piece = (AT_HD == 64) ? (gi >> 1) * PPB + p : gi * PPB + p % PPB;     // 1-KiB piece of that matrix
     const int r = piece * G::RPP + prow;
     const int lchunk = G::swz(r, pchunk);
-    const void *src = (r < N) ? (const void *)(base + (size_t)r * ld + (1 + mat) * C + lchunk * 8)
-                              : (const void *)(g_att_zero + lane * 16);
+    const void *src = (FULL || r < N) ? (const void *)(base + (size_t)r * ld + (1 + mat) * C + lchunk * 8)
+                                      : (const void *)(g_att_zero + lane * 16);
     att_glds16(src, __builtin_amdgcn_readfirstlane(lds0 + mat * (AT_NMAX * AT_KROW) + piece * 1024));
   };
-  if constexpr (PIPE) {
-    // ---- Q fragments first (B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]), by loads the compiler
-    // does not count; rows >= N read the zero line
-#pragma unroll
-    for (int t = 0; t < AT_QT; ++t) {
-      const int q = q0 + t * 16 + lrow;
-#pragma unroll
-      for (int s = 0; s < G::KS; ++s)
-        qf[t][s] = att_gload16(q < N ? (const void *)(base + (size_t)q * ld + s * 32 + g * 8)
-                                     : (const void *)(g_att_zero + lane * 16));
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) issue_piece(0, j);      // group 0 now; the others are issued inside the first product
-  } else {
-  // ---- stage K and V into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, 24 one-KiB
-  // pieces per wave issued back to back, one wait), both row-major; the 16-B chunk XOR swizzle is
-  // applied on the per-lane SOURCE address so the LDS image stays lane-linear.  Rows >= N read a
-  // zero line.  V is NOT transposed here: the second product reads it through ds_read_b64_tr_b16.
-  {
-    constexpr int PIECES_W = AT_NMAX / G::RPP / 4;       // 1-KiB pieces per wave, for K and for V
-    const int prow = lane / G::CHUNKS, pchunk = lane % G::CHUNKS;
-#pragma unroll
-    for (int j = 0; j < PIECES_W; ++j) {
-      const int r = (wave * PIECES_W + j) * G::RPP + prow;
-      const int lchunk = G::swz(r, pchunk);
-      const bf16_t *src = (r < N) ? base + (size_t)r * ld + lchunk * 8 : nullptr;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (wave * PIECES_W + j) * 1024);
-      att_glds16(src ? (const void *)(src + C) : (const void *)(g_att_zero + lane * 16), dst);
-      att_glds16(src ? (const void *)(src + 2 * C) : (const void *)(g_att_zero + lane * 16), dst + AT_NMAX * AT_KROW);
-    }
-  }
-
-  // ---- Q fragments straight from global: B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]
+  // ---- Q fragments first (B operand, lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]).  Ordinary loads, and the
+  // OLDEST memory operations of the wave: the waits the compiler places for them count only these six, which with
+  // younger DMA in flight is conservative, never short.  (Loads hidden from the compiler in inline asm are not safe
+  // here: it may copy their destination registers before the data has landed.)
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
     const int q = q0 + t * 16 + lrow;
 #pragma unroll
     for (int s = 0; s < G::KS; ++s) {
       qf[t][s] = make_uint4(0, 0, 0, 0);
-      if (q < N) qf[t][s] = *reinterpret_cast<const uint4 *>(base + (size_t)q * ld + s * 32 + g * 8);
+      if (FULL || q < N) qf[t][s] = *reinterpret_cast<const uint4 *>(base + (size_t)q * ld + s * 32 + g * 8);
     }
   }
-  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) issue_piece(0, j);        // group 0 now; the others are issued inside the first product
   ATT_STAMP(t1);
-  if constexpr (PIPE) {
-    att_wait_barrier<0>();                             // Q and the first group have landed, for every wave
-#pragma unroll
-    for (int t = 0; t < AT_QT; ++t)
-#pragma unroll
-      for (int s = 0; s < G::KS; ++s)     // uses of Q stay below the wait
-        asm volatile("" : "+v"(qf[t][s].x), "+v"(qf[t][s].y), "+v"(qf[t][s].z), "+v"(qf[t][s].w));
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA pieces (and the Q loads) have landed
-    __syncthreads();
-  }
+  att_wait_barrier<0>();                               // Q and the first group have landed, for every wave
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // the same vmcnt(0), visible to the compiler: no later Q waits
   ATT_STAMP(t2);
 
   // ---- two key blocks of 96 keys, flash style: only 6 x QT score tiles (72 registers) are live at a
@@ -229,17 +186,16 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
 #endif
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    if constexpr (PIPE) {
-      if (kb == 1) att_wait_barrier<(AT_HD == 64) ? 3 : 0>();      // K (hd 32: K and V) of block 1
-    }
+    if (kb == 1) att_wait_barrier<(AT_HD == 64) ? 3 : 0>();        // K (hd 32: K and V) of block 1
     // S^T block = K_block Q^T : sacc[kt][t] rows = keys 96*kb + 16*kt + 4g + r, col = query
     f32x4 sacc[KB_TILES][AT_QT];
 #pragma unroll
     for (int kt = 0; kt < KB_TILES; ++kt) {
       // keys >= N (zero rows in LDS) start at -inf, so their scores stay -inf and their weights 0
       const int key_lo = (kb * KB_TILES + kt) * 16 + g * 4;
-      const f32x4 init = f32x4{key_lo + 0 < N ? 0.f : -__builtin_inff(), key_lo + 1 < N ? 0.f : -__builtin_inff(),
-                               key_lo + 2 < N ? 0.f : -__builtin_inff(), key_lo + 3 < N ? 0.f : -__builtin_inff()};
+      const f32x4 init = FULL ? f32x4{0.f, 0.f, 0.f, 0.f}
+                              : f32x4{key_lo + 0 < N ? 0.f : -__builtin_inff(), key_lo + 1 < N ? 0.f : -__builtin_inff(),
+                                      key_lo + 2 < N ? 0.f : -__builtin_inff(), key_lo + 3 < N ? 0.f : -__builtin_inff()};
 #pragma unroll
       for (int t = 0; t < AT_QT; ++t) sacc[kt][t] = init;
       const int r = (kb * KB_TILES + kt) * 16 + lrow;
@@ -252,13 +208,11 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
                                                                 *reinterpret_cast<const bf16x8 *>(&qf[t][s]),
                                                                 sacc[kt][t], 0, 0, 0);
       }
-      if constexpr (PIPE) {
-        // the rest of K / V is requested here, spread over the first product, so that no wave sits in the (memory-
-        // throttled) issue of all 18 loads before it computes
-        if (kb == 0) {
+      // the rest of K / V is requested here, spread over the first product, so that no wave sits in the (memory-
+      // throttled) issue of all 18 loads before it computes
+      if (kb == 0) {
 #pragma unroll
-          for (int i = kt * NLATE / KB_TILES; i < (kt + 1) * NLATE / KB_TILES; ++i) issue_piece(1 + i / 3, i % 3);
-        }
+        for (int i = kt * NLATE / KB_TILES; i < (kt + 1) * NLATE / KB_TILES; ++i) issue_piece(1 + i / 3, i % 3);
       }
     }
     // online softmax over this block's keys, per query column.  VALU diet (this phase, not the MFMAs,
@@ -310,7 +264,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       }
     }
     // O^T += V_block^T P_block^T : rows = dims 16*dt + 4g + r, col = query
-    if constexpr (PIPE && AT_HD == 64) {
+    if constexpr (AT_HD == 64) {
       if (kb == 0) att_wait_barrier<6>(); else att_wait_barrier<0>();   // V of this block
     }
 #pragma unroll
@@ -366,7 +320,7 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
 #pragma unroll
   for (int t = 0; t < AT_QT; ++t) {
     const int q = q0 + t * 16 + lrow;
-    if (q >= N) continue;
+    if (!FULL && q >= N) continue;
     if (fp8_inv_scale > 0.f) {   // out is an e4m3 byte tensor [B*N, C]
       unsigned char *orow8 = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * C + h * AT_HD;
       const float sc = inv_l[t] * fp8_inv_scale;
@@ -396,16 +350,16 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
 #endif
 }
 
-// ---- streaming form: any N, head_dim 32 / 64 / 80.  Workgroup = 4 waves x ST_QT query tiles = 128
-// queries of one (crop, head); key blocks of ST_KB = 96 rows of K and V go HBM/L2 -> LDS by LDS-DMA
-// (single-buffered: three workgroups share a CU and cover each other's load phases), then exactly the
-// block body of the kernel above.  Rows are addressed block-relative in LDS; masks use the global key.
-constexpr int ST_QT = 2;
-constexpr int ST_KB = 96;
-template <int HD>
-__global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *__restrict__ qkv,
+// ---- streaming form: any N, head_dim 32 / 64 / 80.  Workgroup = NW waves x ST_QT query tiles (4 x 2 = 128 or
+// 3 x 3 = 144 queries, whichever wastes fewer query rows: N = 432 is 3 x 144) of one (crop, head); key blocks of ST_KB
+// rows of K and V go HBM/L2 -> LDS by LDS-DMA into a two-deep ring -- block kb + 1 is requested before block kb is
+// computed, one barrier per block -- then exactly the block body of the kernel above.  Rows are addressed
+// block-relative in LDS; masks use the global key.
+template <int HD, int NW, int ST_QT, int ST_KB>
+__global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16_t *__restrict__ qkv,
                                                                   bf16_t *__restrict__ out, int N, int heads,
-                                                                  int qblocks, float scale_log2e, float fp8_inv_scale) {
+                                                                  int qblocks, int nprob, float scale_log2e,
+                                                                      float fp8_inv_scale) {
   using G = AttGeom<HD>;
   constexpr int KROW = G::KROW;
   constexpr int BLK_BYTES = ST_KB * KROW;
@@ -413,9 +367,11 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
   constexpr int NPIECE = BLK_BYTES / 1024;
   constexpr int KB_TILES = ST_KB / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *Ks = smem;
-  char *Vs = smem + BLK_BYTES;
-  const int qb = blockIdx.x % qblocks, bh = blockIdx.x / qblocks;
+  // XCD-aware order: workgroups go round-robin to the 8 XCDs, each with its own L2, so the query blocks of one
+  // (crop, head) are made consecutive WITHIN an XCD's share: its K / V blocks cross the fabric once, not qblocks times
+  const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3;
+  const int qb = wx % qblocks, bh = (wx / qblocks) * 8 + xcd;
+  if (bh >= nprob) return;                   // the grid is rounded up to whole groups of 8 problems
   const int b = bh / heads, h = bh - b * heads;
   const int C = heads * HD, ld = 3 * C;
   const bf16_t *base = qkv + (size_t)b * N * ld + h * HD;
@@ -424,7 +380,7 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
   // Q fragments (B operand): lane (col q = lrow, g) holds Q[q][32s + 8g .. +7]; dims >= HD are zero
-  const int q0 = (qb * 4 + wave) * (ST_QT * 16);
+  const int q0 = (qb * NW + wave) * (ST_QT * 16);
   uint4 qf[ST_QT][G::KS];
 #pragma unroll
   for (int t = 0; t < ST_QT; ++t) {
@@ -447,25 +403,32 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
   }
 
   const int nkb = (N + ST_KB - 1) / ST_KB;   // every block holds at least one real key
-  for (int kb = 0; kb < nkb; ++kb) {
-    if (kb > 0) __syncthreads();             // every wave has finished reading the previous block
-    // ---- K / V block -> LDS: piece p = 64 consecutive 16-B chunks of the row-major block image
+  // K / V block kb -> ring slot kb & 1: piece p = 64 consecutive 16-B chunks of the row-major block image
+  auto issue_block = [&](int kb) __attribute__((always_inline)) {
+    const unsigned slot = lds0 + (kb & 1) * (2 * BLK_BYTES);
 #pragma unroll
-    for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
-      const int pc = j * 4 + wave;
+    for (int j = 0; j < (NPIECE + NW - 1) / NW; ++j) {
+      const int pc = j * NW + wave;
       if (pc < NPIECE) {
         const int c = pc * 64 + lane;
         const int row = c / G::CHUNKS, pchunk = c - row * G::CHUNKS;
         const int key = kb * ST_KB + row;
         const bf16_t *src = base + (size_t)key * ld + G::swz(row, pchunk) * 8;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + pc * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(slot + pc * 1024);
         const void *zsrc = g_att_zero + lane * 16;
         att_glds16(key < N ? (const void *)(src + C) : zsrc, dst);
         att_glds16(key < N ? (const void *)(src + 2 * C) : zsrc, dst + BLK_BYTES);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+  issue_block(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    // block kb has landed (the only DMA in flight) for every wave, and every wave is done with block kb - 1, whose
+    // slot the next request overwrites
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (kb + 1 < nkb) issue_block(kb + 1);
+    const char *Ks = smem + (kb & 1) * (2 * BLK_BYTES);
+    const char *Vs = Ks + BLK_BYTES;
 
     // ---- S^T block = K_block Q^T
     f32x4 sacc[KB_TILES][ST_QT];
@@ -600,13 +563,28 @@ __global__ __launch_bounds__(256, 3) void attention_stream_kernel(const bf16_t *
   }
 }
 
-template <int HD>
-static void launch_stream(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s) {
-  const int qblocks = (N + 4 * ST_QT * 16 - 1) / (4 * ST_QT * 16);
+template <int HD, int NW, int QT, int KB>
+static int launch_stream_cfg(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s) {
+  const int qblocks = (N + NW * QT * 16 - 1) / (NW * QT * 16);
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
-  hipLaunchKernelGGL(attention_stream_kernel<HD>, dim3((unsigned)((size_t)B * heads * qblocks)), dim3(256),
-                     2 * ST_KB * AttGeom<HD>::KROW, s, (const bf16_t *)qkv, (bf16_t *)out, N, heads, qblocks,
-                     scale_log2e, fp8_inv_scale);
+  const int nprob = B * heads;
+  constexpr int LDS = 4 * KB * AttGeom<HD>::KROW;     // two slots of K + V
+  hipLaunchKernelGGL((attention_stream_kernel<HD, NW, QT, KB>), dim3((unsigned)((size_t)((nprob + 7) / 8) * 8 * qblocks)),
+                     dim3(NW * 64), LDS, s, (const bf16_t *)qkv, (bf16_t *)out, N, heads, qblocks, nprob, scale_log2e,
+                     fp8_inv_scale);
+  return 0;
+}
+
+// 144-query workgroups (3 waves x 3 tiles) when they waste fewer query rows than 128-query ones (4 waves x 2); the
+// key block shrinks to 32 rows there (hd 64 / 80: 3 score tiles per key tile would not fit 168 registers otherwise).
+// PP_ATT_STREAM = 4 / 3 forces one form (lab use).
+template <int HD>
+static int launch_stream(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s) {
+  static const int forced = []() { const char *e = getenv("PP_ATT_STREAM"); return e ? atoi(e) : 0; }();
+  const int waste128 = (N + 127) / 128 * 128 - N, waste144 = (N + 143) / 144 * 144 - N;
+  const bool use144 = forced ? forced != 4 : waste144 < waste128;
+  if (use144) return launch_stream_cfg<HD, 3, 3, 32>(qkv, out, B, N, heads, fp8_inv_scale, s);
+  return launch_stream_cfg<HD, 4, 2, 64>(qkv, out, B, N, heads, fp8_inv_scale, s);
 }
 
 }  // namespace pp
@@ -621,15 +599,15 @@ static int attention_dispatch(const void *qkv, void *out, int B, int N, int head
   if (dtype == PP_BF16) {
     if ((hd == 64 || hd == 32) && N <= AT_NMAX && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0) {
       const float scale_log2e = 1.4426950408889634f / sqrtf((float)hd);
-      static const bool pipe = []() { const char *e = getenv("PP_ATT_PIPE"); return !(e && e[0] == '0'); }();
       const dim3 grid(B * heads), block(256);
       const bf16_t *qp = (const bf16_t *)qkv;
       bf16_t *op = (bf16_t *)out;
-      if (hd == 64 && pipe)
+      const bool full = N == AT_NMAX;
+      if (hd == 64 && full)
         hipLaunchKernelGGL((attention_mfma_kernel<64, true>), grid, block, AttGeom<64>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
       else if (hd == 64)
         hipLaunchKernelGGL((attention_mfma_kernel<64, false>), grid, block, AttGeom<64>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
-      else if (pipe)
+      else if (full)
         hipLaunchKernelGGL((attention_mfma_kernel<32, true>), grid, block, AttGeom<32>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
       else
         hipLaunchKernelGGL((attention_mfma_kernel<32, false>), grid, block, AttGeom<32>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
@@ -637,7 +615,7 @@ static int attention_dispatch(const void *qkv, void *out, int B, int N, int head
       return 0;
     }
     if ((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 &&
-        (size_t)B * heads * ((N + 127) / 128) < (1ull << 31)) {
+        ((size_t)B * heads + 8) * ((N + 127) / 128) < (1ull << 31)) {
       if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, fp8_inv_scale, s);
       else if (hd == 64) launch_stream<64>(qkv, out, B, N, heads, fp8_inv_scale, s);
       else launch_stream<32>(qkv, out, B, N, heads, fp8_inv_scale, s);
