@@ -1951,8 +1951,8 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                a->stats_parts, p.tiles_n);
   hipStream_t s = (hipStream_t)stream;
   if (cfg == 14) {
-    // duo form (gemm_duo_kernel): plain bf16 layers, K a multiple of 32
-    PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && batch == 1 && a->Kd % 32 == 0 &&
+    // duo form (gemm_duo_kernel): plain bf16 layers (K a multiple of 64 like every bf16 tile; it stages 32-deep K-tiles)
+    PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && batch == 1 && a->Kd % 64 == 0 &&
                    !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | PP_EPI_RESIDUAL | PP_EPI_OUT_F32 |
                                      PP_EPI_ROWBIAS | (1 << 30))) &&
                    (!(a->epilogue & (PP_EPI_RESIDUAL | PP_EPI_ROWBIAS)) || (a->epilogue & PP_EPI_OUT_F32)) &&
