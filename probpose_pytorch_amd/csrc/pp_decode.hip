@@ -707,6 +707,242 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 #undef DSC
 }
 
+// ---------------------------------------------------------------------------
+// Wave-per-map path (64x48 maps: every 256x192 model).  Same idea as the screened path above -- float32 screening,
+// the float64 chains only at the candidates -- but ONE WAVE owns a map from the load to the result, so there is no
+// workgroup barrier, no shared reduction and no inter-wave hand-off anywhere: 12 maps are in flight per CU (4 waves
+// per workgroup x 3 workgroups), each an independent instruction stream, and the float32 passes run out of registers:
+//   1. the map goes HBM -> LDS once with lane-linear 16-byte loads (12 per lane), A = max |x| comes with it;
+//   2. row pass: lane = row, its W inputs in registers, reflection resolved at compile time;
+//   3. the W x H intermediate crosses the lanes through the same LDS buffer, transposed (conflict-free strides);
+//   4. column pass: lane = column, its H inputs in registers; the H float32 outputs stay in registers;
+//   5. wave max -> threshold -> candidates (ballot) -> exact float64 value of each candidate by T lanes (one row chain
+//      each, the map re-read from L2) + the column chain; then the four neighbours of the winner in one more round of
+//      3T + 2 row chains; finalize() on lane 0.
+// Non-finite maps and flat maps with more than DWV_MAXCAND candidates take the float64 chains at every pixel (one
+// pixel per lane per step): slow, rare, exact.
+// ---------------------------------------------------------------------------
+constexpr int DWV_WAVES = 4;
+constexpr int DWV_MAXCAND = 64;
+
+constexpr __host__ __device__ int reflect_c(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
+
+// steps 2-4 for a compile-time radius; c32[y] = float32 convolved value at (y, lane) for lane < W
+template <int H, int W, int R>
+__device__ __forceinline__ void wave_passes(float *__restrict__ buf, const double *__restrict__ wk, float (&c32)[H]) {
+  constexpr int T = 2 * R + 1, RS = W + 4, TS = H + 4;
+  const int lane = threadIdx.x & 63;
+  float w[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) w[j] = (float)wk[j];
+  {
+    float in[W];
+    const int y = lane < H ? lane : H - 1;
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4 *>(buf + y * RS + 4 * q);
+      in[4 * q + 0] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the whole wave has its rows: the buffer is free
+#pragma unroll
+    for (int x = 0; x < W; ++x) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < T; ++j) a = fmaf(w[j], in[reflect_c(x - R + j, W)], a);
+      if (lane < H) buf[x * TS + lane] = a;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // transposed intermediate is in LDS
+  {
+    float col[H];
+    const int x = lane < W ? lane : W - 1;
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4 *>(buf + x * TS + 4 * q);
+      col[4 * q + 0] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int y = 0; y < H; ++y) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < T; ++j) a = fmaf(w[j], col[reflect_c(y - R + j, H)], a);
+      c32[y] = a;
+    }
+  }
+}
+
+// one float64 row chain of the reference's separable evaluation, read from global (L2-hot) memory
+__device__ __forceinline__ double dwv_row_chain(const float *__restrict__ src, int H, int W, int R,
+                                                const double *__restrict__ wk, int yy, int x) {
+  const float *rp = src + reflect_once(yy, H) * W;
+  double t = 0.0;
+  for (int i = 0; i <= 2 * R; ++i) t = fma(wk[i], (double)rp[reflect_once(x - R + i, W)], t);
+  return t;
+}
+
+template <int H, int W>
+__global__ __launch_bounds__(DWV_WAVES * 64, 3) void decode_wave_kernel(
+    const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
+    int K, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y, double in_w,
+    double in_h, DecodeOut o) {
+  static_assert(H <= 64 && W <= 64 && W % 4 == 0 && H % 4 == 0 && (H * W) % 256 == 0, "wave-per-map geometry");
+  constexpr int HW = H * W, RS = W + 4, TS = H + 4;
+  constexpr int BUF = (H * RS > W * TS ? H * RS : W * TS);
+  static_assert(BUF >= DWV_MAXCAND + 2 * 64 + 16, "candidate list and chain scratch reuse the buffer");
+  __shared__ __attribute__((aligned(16))) float lds[DWV_WAVES][BUF];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int map = blockIdx.x * DWV_WAVES + wave;
+  if (map >= B * K) return;                          // whole waves leave; nothing below synchronises across waves
+  const int k = map % K;
+  float *buf = lds[wave];
+  const float *__restrict__ src = heatmaps + (size_t)map * HW;
+  const int r = __builtin_amdgcn_readfirstlane(radius[k]);
+  const double *__restrict__ wk = taps + (size_t)k * PP_MAX_TAPS;
+
+  // 1. HBM -> LDS (row stride RS), A = max |x| (NaN / inf make the map "not finite")
+  float amax = 0.f, vmin = __builtin_inff(), vmax = -__builtin_inff();
+  bool bad = false;
+  {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+    float4 v[HW / 256];
+#pragma unroll
+    for (int i = 0; i < HW / 256; ++i) v[i] = s4[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < HW / 256; ++i) {
+      const int e = 4 * (i * 64 + lane), y = e / W, x = e - y * W;
+      *reinterpret_cast<float4 *>(buf + y * RS + x) = v[i];
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+      vmin = fminf(fminf(vmin, fminf(v[i].x, v[i].y)), fminf(v[i].z, v[i].w));
+      vmax = fmaxf(fmaxf(vmax, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+      bad |= !(fabsf(v[i].x) <= 3.0e38f) | !(fabsf(v[i].y) <= 3.0e38f) | !(fabsf(v[i].z) <= 3.0e38f) |
+             !(fabsf(v[i].w) <= 3.0e38f);
+    }
+  }
+  const float A = wave_max(amax), gmax = wave_max(vmax), gmin = -wave_max(-vmin);
+  const bool finite = __ballot(bad) == 0ull;
+  if (finite && gmin == gmax) {
+    // constant map: every convolved value is the same number, np.argmax returns index 0 (a border pixel)
+    if (lane == 0) {
+      auto at = [&](int, int) { return 0.f; };
+      finalize(map, B, K, H, W, 0, at, src, prob, vis, oks, err, den_x, den_y, in_w, in_h, o);
+    }
+    return;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the map is in LDS (this wave's own buffer)
+
+  int *cand = reinterpret_cast<int *>(buf);                               // [DWV_MAXCAND], after the passes
+  double *scratch = reinterpret_cast<double *>(buf + DWV_MAXCAND);        // [64] row-chain results
+  int ncand = DWV_MAXCAND + 1;                                            // "every pixel" unless the screen says less
+  if (finite) {
+    float c32[H];
+    switch (r) {
+      case 2: wave_passes<H, W, 2>(buf, wk, c32); break;
+      case 3: wave_passes<H, W, 3>(buf, wk, c32); break;
+      case 4: wave_passes<H, W, 4>(buf, wk, c32); break;
+      case 5: wave_passes<H, W, 5>(buf, wk, c32); break;
+      case 6: wave_passes<H, W, 6>(buf, wk, c32); break;
+      case 7: wave_passes<H, W, 7>(buf, wk, c32); break;
+      case 8: wave_passes<H, W, 8>(buf, wk, c32); break;
+      default: wave_passes<H, W, 9>(buf, wk, c32); break;
+    }
+    float lm = -__builtin_inff();
+#pragma unroll
+    for (int y = 0; y < H; ++y) lm = fmaxf(lm, c32[y]);
+    if (lane >= W) lm = -__builtin_inff();
+    const float m32 = wave_max(lm);
+    const float thr = m32 - 128.0f * 5.9604645e-08f * A;     // see the error budget of the screened path above
+    ncand = 0;
+    if (lane >= W) lm = -__builtin_inff();
+#pragma unroll
+    for (int y = 0; y < H; ++y) {
+      const bool pred = lane < W && c32[y] >= thr;
+      const unsigned long long m = __ballot(pred);
+      if (m) {
+        if (pred) {
+          const int slot = ncand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+          if (slot < DWV_MAXCAND) cand[slot] = y * W + lane;
+        }
+        ncand += __builtin_popcountll(m);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN)
+  const int T = 2 * r + 1;
+  Best best;
+  best.v = -__builtin_inff();
+  best.i = 0x7fffffff;
+  bool have = false;
+  if (ncand <= DWV_MAXCAND) {
+    for (int ci = 0; ci < ncand; ++ci) {
+      const int p = cand[ci], y = p / W, x = p - y * W;
+      if (lane < T) scratch[lane] = dwv_row_chain(src, H, W, r, wk, y - r + lane, x);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      double c = 0.0;
+      for (int j = 0; j < T; ++j) c = fma(wk[j], scratch[j], c);
+      asm volatile("" ::: "memory");
+      const float cv = (float)c;
+      if (!have || better(cv, p, best.v, best.i)) {
+        best.v = cv;
+        best.i = p;
+        have = true;
+      }
+    }
+  } else {
+    // every pixel, one per lane per step: the same two chains, run by one lane
+    for (int p = lane; p < HW; p += 64) {
+      const int y = p / W, x = p - y * W;
+      double c = 0.0;
+      for (int j = 0; j < T; ++j) c = fma(wk[j], dwv_row_chain(src, H, W, r, wk, y - r + j, x), c);
+      const float cv = (float)c;
+      if (!have || better(cv, p, best.v, best.i)) {
+        best.v = cv;
+        best.i = p;
+        have = true;
+      }
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) {
+      const float ov = __shfl_xor(best.v, o_, 64);
+      const int oi = __shfl_xor(best.i, o_, 64);
+      if (better(ov, oi, best.v, best.i)) {
+        best.v = ov;
+        best.i = oi;
+      }
+    }
+  }
+  // exact neighbours of the winner (interior only): lanes [0, T) column x + 1, [T, 2T) column x - 1, [2T, 3T + 2)
+  // column x over rows y - 1 - r .. y + 1 + r; then four column chains on lanes 0..3
+  const int bx = best.i % W, by = best.i / W;
+  const bool interior = bx > 0 && bx < W - 1 && by > 0 && by < H - 1;
+  float nb = 0.f;                 // lane q < 4: value at (x + 1), (x - 1), (y + 1), (y - 1)
+  if (interior) {
+    if (lane < 3 * T + 2) {
+      const int grp = lane < T ? 0 : (lane < 2 * T ? 1 : 2);
+      const int idx = lane - grp * T;
+      const int xx = grp == 0 ? bx + 1 : (grp == 1 ? bx - 1 : bx);
+      const int yy = grp == 2 ? by - 1 - r + idx : by - r + idx;
+      scratch[lane] = dwv_row_chain(src, H, W, r, wk, yy, xx);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 4) {
+      const int base = lane == 0 ? 0 : (lane == 1 ? T : (lane == 2 ? 2 * T + 2 : 2 * T));
+      double c = 0.0;
+      for (int j = 0; j < T; ++j) c = fma(wk[j], scratch[base + j], c);
+      nb = (float)c;
+    }
+  }
+  const float n_xp = __shfl(nb, 0, 64), n_xm = __shfl(nb, 1, 64), n_yp = __shfl(nb, 2, 64), n_ym = __shfl(nb, 3, 64);
+  if (lane == 0) {
+    auto at = [&](int yy, int xx) {
+      return yy == by ? (xx == bx ? best.v : (xx == bx + 1 ? n_xp : n_xm)) : (yy == by + 1 ? n_yp : n_ym);
+    };
+    finalize(map, B, K, H, W, best.i, at, src, prob, vis, oks, err, den_x, den_y, in_w, in_h, o);
+  }
+}
+
 static size_t screen_lds_bytes(int H, int W) {
   return ((size_t)H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) + (size_t)H * W + DF_MAXCAND) * 4;
 }
@@ -814,6 +1050,14 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   // maps 24.3 vs 22.9 us at B = 64 and 236 vs 234 us at B = 1024 (a tie: both forms are bound by the latency of their
   // short barrier-separated phases, not by HBM, LDS or the FMA rate).  The screened form is the default where it
   // wins (maps larger than 4096 pixels); PP_DECODE_SCREEN=1 forces it everywhere, PP_DECODE_EXACT_ALL=1 never.
+  // wave-per-map kernel: the 64x48 maps of every 256x192 model (PP_DECODE_WAVE=0 turns it off for A/B runs)
+  static const bool wave_off = []() { const char *e = getenv("PP_DECODE_WAVE"); return e && e[0] == '0'; }();
+  if (!out_conv && !wave_off && !getenv_exact() && H == 64 && W == 48 && ((uintptr_t)heatmaps & 15) == 0) {
+    hipLaunchKernelGGL((decode_wave_kernel<64, 48>), dim3((unsigned)cdiv(maps, DWV_WAVES)), dim3(DWV_WAVES * 64), 0, s,
+                       heatmaps, prob, vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o);
+    PP_CHECK_LAUNCH("decode_wave_kernel");
+    return 0;
+  }
   const bool want_screen = getenv_flag("PP_DECODE_SCREEN") || (long long)H * W > 4096;
   if (!out_conv && want_screen && !getenv_exact() && screen_lds_bytes(H, W) <= SCREEN_DYN_LIMIT) {
     const size_t lds = screen_lds_bytes(H, W);
