@@ -708,58 +708,97 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 }
 
 // ---------------------------------------------------------------------------
-// Wave-per-map path (64x48 maps: every 256x192 model).  Same idea as the screened path above -- float32 screening,
-// the float64 chains only at the candidates -- but ONE WAVE owns a map from the load to the result, so there is no
-// workgroup barrier, no shared reduction and no inter-wave hand-off anywhere: 12 maps are in flight per CU (4 waves
-// per workgroup x 3 workgroups), each an independent instruction stream, and the float32 passes run out of registers:
-//   1. the map goes HBM -> LDS once with lane-linear 16-byte loads (12 per lane), A = max |x| comes with it;
-//   2. row pass: lane = row, its W inputs in registers, reflection resolved at compile time;
-//   3. the W x H intermediate crosses the lanes through the same LDS buffer, transposed (conflict-free strides);
-//   4. column pass: lane = column, its H inputs in registers; the H float32 outputs stay in registers;
-//   5. wave max -> threshold -> candidates (ballot) -> exact float64 value of each candidate by T lanes (one row chain
-//      each, the map re-read from L2) + the column chain; then the four neighbours of the winner in one more round of
-//      3T + 2 row chains; finalize() on lane 0.
+// Wave-per-map path (64x48 maps: every 256x192 model; 96x72: the 384x288 models).  Same idea as the screened path
+// above -- float32 screening, the float64 chains only at the candidates -- but ONE WAVE owns a map from the load to
+// the result, so there is no workgroup barrier, no shared reduction and no inter-wave hand-off anywhere: 12 maps
+// (64x48) or 5 (96x72) are in flight per CU, each an independent instruction stream, and the float32 passes run out
+// of registers:
+//   1. the map goes HBM -> LDS once with lane-linear 16-byte loads, A = max |x| comes with it;
+//   2. row pass: lane = row (NRI rounds of HI = H / NRI rows), its W inputs in registers, reflection resolved at
+//      compile time;
+//   3. the intermediate crosses the lanes through the SAME LDS buffer, transposed: round i writes a [W][HI + pad]
+//      image over the raw rows it has just consumed (conflict-free strides both ways);
+//   4. column pass: lane = column (NCI rounds of WI = W / NCI columns), its H inputs in registers; the float32
+//      results go back over the column they came from, the lane keeps only its maximum;
+//   5. wave max -> threshold -> the columns that reach it are scanned by the whole wave (one row per lane) ->
+//      candidates -> exact float64 value of each candidate by T lanes (one row chain each, the map re-read from L2) +
+//      the column chain; then the four neighbours of the winner in one more round of 3T + 2 row chains; finalize()
+//      on lane 0.
 // Non-finite maps and flat maps with more than DWV_MAXCAND candidates take the float64 chains at every pixel (one
 // pixel per lane per step): slow, rare, exact.
 // ---------------------------------------------------------------------------
-constexpr int DWV_WAVES = 4;
 constexpr int DWV_MAXCAND = 64;
 
 constexpr __host__ __device__ int reflect_c(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
 
-// steps 2-4 for a compile-time radius; c32[y] = float32 convolved value at (y, lane) for lane < W
-template <int H, int W, int R>
-__device__ __forceinline__ void wave_passes(float *__restrict__ buf, const double *__restrict__ wk, float (&c32)[H]) {
-  constexpr int T = 2 * R + 1, RS = W + 4, TS = H + 4;
+template <int H_, int W_> struct WaveGeom {
+  static constexpr int H = H_, W = W_, HW = H * W;
+  static constexpr int NRI = (H + 63) / 64, HI = H / NRI;        // row-pass rounds, rows per round
+  static constexpr int NCI = (W + 63) / 64, WI = W / NCI;        // column-pass rounds, columns per round
+  static constexpr int RS = W + 4;                               // raw row stride (floats): 16-B rows, conflict-free b128
+  static constexpr int TPAD = NRI == 1 ? 4 : 2;                  // transposed column stride HI + TPAD
+  static constexpr int TS = HI + TPAD;
+  static constexpr int SEG = HI * RS;                            // raw rows of one round = home of its transposed image
+  static constexpr int BUF = H * RS;
+  static constexpr int NLD = HW / 256;                           // 16-byte loads per lane
+  static_assert(H % NRI == 0 && W % NCI == 0 && W % 4 == 0 && HI % 4 == 0 && HW % 256 == 0, "wave-per-map geometry");
+  static_assert(W * TS <= SEG, "a round's transposed image fits over the raw rows it replaces");
+  static_assert(BUF >= DWV_MAXCAND + 2 * 64 + 16, "candidate list and chain scratch reuse the buffer");
+  static_assert(H <= 128 && W <= 128, "two rounds at most are meant");
+};
+
+// steps 2-4 for a compile-time radius; returns the lane's maximum over its columns (lanes without a column: -inf);
+// afterwards tcol(x)[y] holds the float32 convolved value at (y, x)
+template <typename G, int R>
+__device__ __forceinline__ float wave_passes(float *__restrict__ buf, const double *__restrict__ wk) {
+  constexpr int T = 2 * R + 1, H = G::H, W = G::W;
   const int lane = threadIdx.x & 63;
   float w[T];
 #pragma unroll
   for (int j = 0; j < T; ++j) w[j] = (float)wk[j];
-  {
+#pragma unroll
+  for (int ri = 0; ri < G::NRI; ++ri) {
     float in[W];
-    const int y = lane < H ? lane : H - 1;
+    const int y = ri * G::HI + (lane < G::HI ? lane : G::HI - 1);
 #pragma unroll
     for (int q = 0; q < W / 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4 *>(buf + y * RS + 4 * q);
+      const float4 t = *reinterpret_cast<const float4 *>(buf + y * G::RS + 4 * q);
       in[4 * q + 0] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the whole wave has its rows: the buffer is free
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the whole wave has its rows: this round's raw rows are free
+    float *tb = buf + ri * G::SEG;
 #pragma unroll
     for (int x = 0; x < W; ++x) {
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < T; ++j) a = fmaf(w[j], in[reflect_c(x - R + j, W)], a);
-      if (lane < H) buf[x * TS + lane] = a;
+      if (lane < G::HI) tb[x * G::TS + lane] = a;
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // transposed intermediate is in LDS
-  {
-    float col[H];
-    const int x = lane < W ? lane : W - 1;
+  float lm = -__builtin_inff();
 #pragma unroll
-    for (int q = 0; q < H / 4; ++q) {
-      const float4 t = *reinterpret_cast<const float4 *>(buf + x * TS + 4 * q);
-      col[4 * q + 0] = t.x; col[4 * q + 1] = t.y; col[4 * q + 2] = t.z; col[4 * q + 3] = t.w;
+  for (int ci = 0; ci < G::NCI; ++ci) {
+    float col[H];
+    const bool act = lane < G::WI;
+    const int x = ci * G::WI + (act ? lane : G::WI - 1);
+#pragma unroll
+    for (int ri = 0; ri < G::NRI; ++ri) {
+      const float *tp = buf + ri * G::SEG + x * G::TS;
+      if constexpr (G::TPAD == 4) {
+#pragma unroll
+        for (int q = 0; q < G::HI / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4 *>(tp + 4 * q);
+          col[ri * G::HI + 4 * q + 0] = t.x; col[ri * G::HI + 4 * q + 1] = t.y;
+          col[ri * G::HI + 4 * q + 2] = t.z; col[ri * G::HI + 4 * q + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < G::HI / 2; ++q) {
+          const float2 t = *reinterpret_cast<const float2 *>(tp + 2 * q);
+          col[ri * G::HI + 2 * q + 0] = t.x; col[ri * G::HI + 2 * q + 1] = t.y;
+        }
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -767,9 +806,14 @@ __device__ __forceinline__ void wave_passes(float *__restrict__ buf, const doubl
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < T; ++j) a = fmaf(w[j], col[reflect_c(y - R + j, H)], a);
-      c32[y] = a;
+      if (act) {
+        buf[(y / G::HI) * G::SEG + x * G::TS + (y % G::HI)] = a;       // back over the column it came from
+        lm = fmaxf(lm, a);
+      }
     }
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return lm;
 }
 
 // one float64 row chain of the reference's separable evaluation, read from global (L2-hot) memory
@@ -781,18 +825,16 @@ __device__ __forceinline__ double dwv_row_chain(const float *__restrict__ src, i
   return t;
 }
 
-template <int H, int W>
-__global__ __launch_bounds__(DWV_WAVES * 64, 3) void decode_wave_kernel(
+template <int H, int W, int NWV>
+__global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
     const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
     int K, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y, double in_w,
     double in_h, DecodeOut o) {
-  static_assert(H <= 64 && W <= 64 && W % 4 == 0 && H % 4 == 0 && (H * W) % 256 == 0, "wave-per-map geometry");
-  constexpr int HW = H * W, RS = W + 4, TS = H + 4;
-  constexpr int BUF = (H * RS > W * TS ? H * RS : W * TS);
-  static_assert(BUF >= DWV_MAXCAND + 2 * 64 + 16, "candidate list and chain scratch reuse the buffer");
-  __shared__ __attribute__((aligned(16))) float lds[DWV_WAVES][BUF];
+  using G = WaveGeom<H, W>;
+  constexpr int HW = G::HW;
+  __shared__ __attribute__((aligned(16))) float lds[NWV][G::BUF];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int map = blockIdx.x * DWV_WAVES + wave;
+  const int map = blockIdx.x * NWV + wave;
   if (map >= B * K) return;                          // whole waves leave; nothing below synchronises across waves
   const int k = map % K;
   float *buf = lds[wave];
@@ -805,18 +847,24 @@ __global__ __launch_bounds__(DWV_WAVES * 64, 3) void decode_wave_kernel(
   bool bad = false;
   {
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    float4 v[HW / 256];
+    constexpr int CH = 9;                              // loads in flight per lane
 #pragma unroll
-    for (int i = 0; i < HW / 256; ++i) v[i] = s4[i * 64 + lane];
+    for (int i0 = 0; i0 < G::NLD; i0 += CH) {
+      float4 v[CH];
 #pragma unroll
-    for (int i = 0; i < HW / 256; ++i) {
-      const int e = 4 * (i * 64 + lane), y = e / W, x = e - y * W;
-      *reinterpret_cast<float4 *>(buf + y * RS + x) = v[i];
-      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
-      vmin = fminf(fminf(vmin, fminf(v[i].x, v[i].y)), fminf(v[i].z, v[i].w));
-      vmax = fmaxf(fmaxf(vmax, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
-      bad |= !(fabsf(v[i].x) <= 3.0e38f) | !(fabsf(v[i].y) <= 3.0e38f) | !(fabsf(v[i].z) <= 3.0e38f) |
-             !(fabsf(v[i].w) <= 3.0e38f);
+      for (int i = 0; i < CH; ++i)
+        if (i0 + i < G::NLD) v[i] = s4[(i0 + i) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        if (i0 + i >= G::NLD) continue;
+        const int e = 4 * ((i0 + i) * 64 + lane), y = e / W, x = e - y * W;
+        *reinterpret_cast<float4 *>(buf + y * G::RS + x) = v[i];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+        vmin = fminf(fminf(vmin, fminf(v[i].x, v[i].y)), fminf(v[i].z, v[i].w));
+        vmax = fmaxf(fmaxf(vmax, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        bad |= !(fabsf(v[i].x) <= 3.0e38f) | !(fabsf(v[i].y) <= 3.0e38f) | !(fabsf(v[i].z) <= 3.0e38f) |
+               !(fabsf(v[i].w) <= 3.0e38f);
+      }
     }
   }
   const float A = wave_max(amax), gmax = wave_max(vmax), gmin = -wave_max(-vmin);
@@ -831,45 +879,60 @@ __global__ __launch_bounds__(DWV_WAVES * 64, 3) void decode_wave_kernel(
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the map is in LDS (this wave's own buffer)
 
-  int *cand = reinterpret_cast<int *>(buf);                               // [DWV_MAXCAND], after the passes
-  double *scratch = reinterpret_cast<double *>(buf + DWV_MAXCAND);        // [64] row-chain results
-  int ncand = DWV_MAXCAND + 1;                                            // "every pixel" unless the screen says less
+  int cand_r[(DWV_MAXCAND + 63) / 64];                       // candidate ci lives in lane ci % 64 (register, not LDS:
+  cand_r[0] = 0;                                             // the buffer still holds the convolved map while they are found)
+  int ncand = DWV_MAXCAND + 1;                               // "every pixel" unless the screen says less
   if (finite) {
-    float c32[H];
+    float lm;
     switch (r) {
-      case 2: wave_passes<H, W, 2>(buf, wk, c32); break;
-      case 3: wave_passes<H, W, 3>(buf, wk, c32); break;
-      case 4: wave_passes<H, W, 4>(buf, wk, c32); break;
-      case 5: wave_passes<H, W, 5>(buf, wk, c32); break;
-      case 6: wave_passes<H, W, 6>(buf, wk, c32); break;
-      case 7: wave_passes<H, W, 7>(buf, wk, c32); break;
-      case 8: wave_passes<H, W, 8>(buf, wk, c32); break;
-      default: wave_passes<H, W, 9>(buf, wk, c32); break;
+      case 2: lm = wave_passes<G, 2>(buf, wk); break;
+      case 3: lm = wave_passes<G, 3>(buf, wk); break;
+      case 4: lm = wave_passes<G, 4>(buf, wk); break;
+      case 5: lm = wave_passes<G, 5>(buf, wk); break;
+      case 6: lm = wave_passes<G, 6>(buf, wk); break;
+      case 7: lm = wave_passes<G, 7>(buf, wk); break;
+      case 8: lm = wave_passes<G, 8>(buf, wk); break;
+      default: lm = wave_passes<G, 9>(buf, wk); break;
     }
-    float lm = -__builtin_inff();
-#pragma unroll
-    for (int y = 0; y < H; ++y) lm = fmaxf(lm, c32[y]);
-    if (lane >= W) lm = -__builtin_inff();
     const float m32 = wave_max(lm);
     const float thr = m32 - 128.0f * 5.9604645e-08f * A;     // see the error budget of the screened path above
+    // columns whose maximum reaches the threshold (usually one) are scanned by the whole wave, one row per lane.
+    // A lane holds the maximum over its NCI columns, so every column of a flagged lane is scanned.
     ncand = 0;
-    if (lane >= W) lm = -__builtin_inff();
+    unsigned long long flagged = __ballot(lm >= thr);
+    while (flagged) {
+      const int fl = __builtin_ctzll(flagged);
+      flagged &= flagged - 1;
 #pragma unroll
-    for (int y = 0; y < H; ++y) {
-      const bool pred = lane < W && c32[y] >= thr;
-      const unsigned long long m = __ballot(pred);
-      if (m) {
-        if (pred) {
-          const int slot = ncand + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-          if (slot < DWV_MAXCAND) cand[slot] = y * W + lane;
+      for (int ci = 0; ci < G::NCI; ++ci) {
+        const int x = ci * G::WI + fl;
+#pragma unroll
+        for (int y0 = 0; y0 < H; y0 += 64) {
+          const int y = y0 + lane;
+          const bool pred = y < H && buf[(y / G::HI) * G::SEG + x * G::TS + (y % G::HI)] >= thr;
+          const unsigned long long m = __ballot(pred);
+          // candidate number ncand + q is kept by lane ncand + q: that lane fetches it from the q-th set lane of m
+          const int cnt = __builtin_popcountll(m);
+          if (cnt && ncand + cnt <= DWV_MAXCAND) {
+            // slot s = ncand + rank (< 64): lane s takes the value from the rank-th set lane of m
+            const int want = lane - ncand;                    // rank this lane's slot asks for
+            int srcl = 0;
+            if (want >= 0 && want < cnt) {
+              unsigned long long mm = m;
+              for (int q = 0; q < want; ++q) mm &= mm - 1;
+              srcl = __builtin_ctzll(mm);
+            }
+            const int got = __shfl(y * W + x, srcl, 64);
+            if (want >= 0 && want < cnt) cand_r[0] = got;
+          }
+          ncand += cnt;
         }
-        ncand += __builtin_popcountll(m);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
-  // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN)
+  // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN).  The buffer is free from here on.
+  double *scratch = reinterpret_cast<double *>(buf);         // [64] row-chain results
   const int T = 2 * r + 1;
   Best best;
   best.v = -__builtin_inff();
@@ -877,12 +940,12 @@ __global__ __launch_bounds__(DWV_WAVES * 64, 3) void decode_wave_kernel(
   bool have = false;
   if (ncand <= DWV_MAXCAND) {
     for (int ci = 0; ci < ncand; ++ci) {
-      const int p = cand[ci], y = p / W, x = p - y * W;
+      const int p = __shfl(cand_r[0], ci, 64), y = p / W, x = p - y * W;
       if (lane < T) scratch[lane] = dwv_row_chain(src, H, W, r, wk, y - r + lane, x);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       double c = 0.0;
       for (int j = 0; j < T; ++j) c = fma(wk[j], scratch[j], c);
-      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const float cv = (float)c;
       if (!have || better(cv, p, best.v, best.i)) {
         best.v = cv;
@@ -1050,11 +1113,17 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   // maps 24.3 vs 22.9 us at B = 64 and 236 vs 234 us at B = 1024 (a tie: both forms are bound by the latency of their
   // short barrier-separated phases, not by HBM, LDS or the FMA rate).  The screened form is the default where it
   // wins (maps larger than 4096 pixels); PP_DECODE_SCREEN=1 forces it everywhere, PP_DECODE_EXACT_ALL=1 never.
-  // wave-per-map kernel: the 64x48 maps of every 256x192 model (PP_DECODE_WAVE=0 turns it off for A/B runs)
-  static const bool wave_off = []() { const char *e = getenv("PP_DECODE_WAVE"); return e && e[0] == '0'; }();
-  if (!out_conv && !wave_off && !getenv_exact() && H == 64 && W == 48 && ((uintptr_t)heatmaps & 15) == 0) {
-    hipLaunchKernelGGL((decode_wave_kernel<64, 48>), dim3((unsigned)cdiv(maps, DWV_WAVES)), dim3(DWV_WAVES * 64), 0, s,
-                       heatmaps, prob, vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o);
+  // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288); PP_DECODE_WAVE=0 turns it off (A/B runs)
+  const char *wave_env = getenv("PP_DECODE_WAVE");
+  const bool wave_off = wave_env && wave_env[0] == '0';
+  if (!out_conv && !wave_off && !getenv_exact() && ((uintptr_t)heatmaps & 15) == 0 &&
+      ((H == 64 && W == 48) || (H == 96 && W == 72))) {
+    if (H == 64)
+      hipLaunchKernelGGL((decode_wave_kernel<64, 48, 4>), dim3((unsigned)cdiv(maps, 4)), dim3(256), 0, s, heatmaps, prob,
+                         vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o);
+    else
+      hipLaunchKernelGGL((decode_wave_kernel<96, 72, 1>), dim3((unsigned)maps), dim3(64), 0, s, heatmaps, prob, vis, oks,
+                         err, B, K, taps, radius, den_x, den_y, in_w, in_h, o);
     PP_CHECK_LAUNCH("decode_wave_kernel");
     return 0;
   }

@@ -134,6 +134,10 @@ def test_edge_maps_zero_flat_ties_negative_nan(pp):
     assert np.isnan(got_c[7]).any()
     np.testing.assert_array_equal(np.isnan(got_c[7]), np.isnan(want_c[7]))
     np.testing.assert_array_equal(got_l[7], want_l[7])
+    # the same maps through the default (candidate-screened, wave-per-map) decode, which returns no convolved map
+    fast_l, fast_v = pp.get_heatmap_expected_value(hm, sig)
+    np.testing.assert_array_equal(fast_l, got_l)
+    np.testing.assert_array_equal(fast_v, got_v)
 
 
 def test_empty_batch(pp):
@@ -225,27 +229,39 @@ def test_encode_batched_equals_per_crop_oracle(pp):
 
 
 def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
-    """The default decode evaluates the float64 convolution only at the float32-screened candidates
-    (decode_screen_kernel); PP_DECODE_EXACT_ALL=1 selects the all-pixel float64 kernel.  Both must return identical
-    numbers on random, peaked, flat, saturated, tied, negative, non-finite and tiny maps."""
+    """The default decode evaluates the float64 convolution only at the float32-screened candidates: one wave per map
+    (decode_wave_kernel) on 64x48 and 96x72 maps, one workgroup per map (decode_screen_kernel; PP_DECODE_WAVE=0 +
+    PP_DECODE_SCREEN=1 force it everywhere) otherwise; PP_DECODE_EXACT_ALL=1 selects the all-pixel float64 kernel.
+    All three must return identical numbers on random, peaked, flat, saturated, tied, negative, non-finite and tiny
+    maps."""
     import torch
     rng = np.random.default_rng(77)
     cases = []
     cases.append(orc.synthetic_heatmaps(6, 17, 64, 48, seed=5, kind="peaked"))
     cases.append(orc.synthetic_heatmaps(3, 17, 64, 48, seed=6, kind="uniform"))
     cases.append(orc.synthetic_heatmaps(2, 133, 96, 72, seed=7, kind="peaked"))
-    sat = np.zeros((2, 17, 64, 48), np.float32)
-    sat[:, :, 10:50, 5:40] = 1.0                                        # clamped plateau: hundreds of exact ties
-    sat[1, 3] = 0.25                                                     # constant map
-    sat[1, 4] = 0.0
-    sat[1, 5, 0, 0] = 1.0                                                # corner peak
-    sat[1, 6, 63, 47] = 1.0
-    sat[1, 7] = rng.random((64, 48), dtype=np.float32) * 1e-6            # tiny values: threshold scales with max |x|
-    sat[1, 8] = -rng.random((64, 48), dtype=np.float32)                  # negative map
-    sat[1, 9, 20, 20] = np.nan
-    sat[1, 10, 5, 5] = np.inf
-    sat[1, 11] = np.round(rng.random((64, 48), dtype=np.float32) * 3) / 3   # many exact ties at several levels
-    cases.append(sat)
+    cases.append(orc.synthetic_heatmaps(1, 133, 96, 72, seed=8, kind="uniform"))
+
+    def hard(H, W):
+        sat = np.zeros((2, 17, H, W), np.float32)
+        sat[:, :, 10:50, 5:40] = 1.0                                    # clamped plateau: hundreds of exact ties
+        sat[1, 3] = 0.25                                                 # constant map
+        sat[1, 4] = 0.0
+        sat[1, 5, 0, 0] = 1.0                                            # corner peak
+        sat[1, 6, H - 1, W - 1] = 1.0
+        sat[1, 7] = rng.random((H, W), dtype=np.float32) * 1e-6          # tiny values: threshold scales with max |x|
+        sat[1, 8] = -rng.random((H, W), dtype=np.float32)                # negative map
+        sat[1, 9, 20, 20] = np.nan
+        sat[1, 10, 5, 5] = np.inf
+        sat[1, 11] = np.round(rng.random((H, W), dtype=np.float32) * 3) / 3   # many exact ties at several levels
+        sat[1, 12, H - 1, 7] = sat[1, 12, 0, W - 2] = 0.5                # equal peaks on two borders
+        sat[1, 13, H // 2, W // 2] = sat[1, 13, H // 2, W // 2 + 1] = 0.75   # two-pixel ridge: > 1 candidate
+        sat[1, 14, 63 % H, 3] = sat[1, 14, (64 % H), 3] = 1.0            # straddles the 64-row round of the big maps
+        sat[1, 15, 30, 35 % W] = sat[1, 15, 30, 36 % W] = 1.0            # straddles the 36-column round
+        return sat
+
+    cases.append(hard(64, 48))
+    cases.append(hard(96, 72))
     cases.append(rng.random((2, 5, 7, 5), dtype=np.float32))            # smaller than the kernel radius
     cases.append(rng.random((1, 3, 33, 27), dtype=np.float32))          # W % 4 != 0
     for hm in cases:
@@ -254,14 +270,19 @@ def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
         codec = pp.Codec(pp.ProbMap((4 * W, 4 * H), (W, H), sig))
         aux = [rng.random((B, K, 1, 1), dtype=np.float32) for _ in range(4)]
         pred = tuple(torch.from_numpy(a).cuda() for a in (hm, *aux))
-        monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
-        monkeypatch.setenv("PP_DECODE_SCREEN", "1")          # the screened form on every map size
-        fast = codec.decode(pred)
+        for v in ("PP_DECODE_EXACT_ALL", "PP_DECODE_SCREEN", "PP_DECODE_WAVE"):
+            monkeypatch.delenv(v, raising=False)
+        legs = {"default": codec.decode(pred)}
+        monkeypatch.setenv("PP_DECODE_WAVE", "0")
+        monkeypatch.setenv("PP_DECODE_SCREEN", "1")          # the workgroup-per-map screened form on every map size
+        legs["screened"] = codec.decode(pred)
         monkeypatch.delenv("PP_DECODE_SCREEN", raising=False)
+        monkeypatch.delenv("PP_DECODE_WAVE", raising=False)
         monkeypatch.setenv("PP_DECODE_EXACT_ALL", "1")
         slow = codec.decode(pred)
         monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
-        np.testing.assert_array_equal(fast[0][0], slow[0][0])
-        np.testing.assert_array_equal(fast[0][1], slow[0][1])
-        for a, b in zip(fast[1:], slow[1:]):
-            np.testing.assert_array_equal(a, b)
+        for name, fast in legs.items():
+            np.testing.assert_array_equal(fast[0][0], slow[0][0], err_msg=f"{name} {hm.shape}")
+            np.testing.assert_array_equal(fast[0][1], slow[0][1], err_msg=f"{name} {hm.shape}")
+            for a, b in zip(fast[1:], slow[1:]):
+                np.testing.assert_array_equal(a, b)
