@@ -747,39 +747,77 @@ template <int H_, int W_> struct WaveGeom {
   static_assert(H <= 128 && W <= 128, "two rounds at most are meant");
 };
 
+// pair i of a register-resident line of 2 * N2 values, i possibly outside [0, N2): scipy 'reflect' maps element e < 0
+// to -e - 1 and e >= N to 2N - 1 - e, which for the pair (2i, 2i + 1) is the SWAPPED pair -i - 1 (resp. 2 N2 - 1 - i)
+template <int N2>
+__device__ __forceinline__ f32x2 pair_r(const f32x2 (&a)[N2], int i) {
+  if (i >= 0 && i < N2) return a[i];
+  const int k = i < 0 ? -i - 1 : 2 * N2 - 1 - i;
+  return (f32x2){a[k].y, a[k].x};
+}
+
+// One float32 pass over a line of 2 * N2 values held as aligned pairs, two outputs per instruction: the taps with an
+// even offset accumulate the output pair (2m, 2m + 1), the taps with an odd offset the pair (2m - 1, 2m), so that
+// EVERY operand is an aligned register pair of the line (no shifted copy); an output is the sum of its two halves.
+// (The float32 result differs from the one-chain order by rounding only: it screens, it does not decide.)
+template <int N2, int R, typename Emit>
+__device__ __forceinline__ void pass_pairs(const f32x2 (&a)[N2], const f32x2 (&w2)[2 * R + 1], Emit emit) {
+  constexpr int T = 2 * R + 1;
+  auto odd_pair = [&](int m) __attribute__((always_inline)) {      // outputs (2m - 1, 2m)
+    f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+      if ((j - R) & 1) acc = __builtin_elementwise_fma(w2[j], pair_r<N2>(a, m + (j - R - 1) / 2), acc);
+    return acc;
+  };
+  f32x2 o_cur = odd_pair(0);
+#pragma unroll
+  for (int m = 0; m < N2; ++m) {
+    f32x2 e = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < T; ++j)
+      if (!((j - R) & 1)) e = __builtin_elementwise_fma(w2[j], pair_r<N2>(a, m + (j - R) / 2), e);
+    const f32x2 o_nxt = odd_pair(m + 1);
+    emit(2 * m, e.x + o_cur.y);
+    emit(2 * m + 1, e.y + o_nxt.x);
+    o_cur = o_nxt;
+  }
+}
+
 // steps 2-4 for a compile-time radius; returns the lane's maximum over its columns (lanes without a column: -inf);
-// afterwards tcol(x)[y] holds the float32 convolved value at (y, x)
+// afterwards the transposed image holds the float32 convolved value of every pixel
 template <typename G, int R>
 __device__ __forceinline__ float wave_passes(float *__restrict__ buf, const double *__restrict__ wk) {
   constexpr int T = 2 * R + 1, H = G::H, W = G::W;
   const int lane = threadIdx.x & 63;
-  float w[T];
+  f32x2 w2[T];
 #pragma unroll
-  for (int j = 0; j < T; ++j) w[j] = (float)wk[j];
+  for (int j = 0; j < T; ++j) {
+    const float wj = (float)wk[j];
+    w2[j] = (f32x2){wj, wj};
+  }
 #pragma unroll
   for (int ri = 0; ri < G::NRI; ++ri) {
-    float in[W];
+    f32x2 in[W / 2];
     const int y = ri * G::HI + (lane < G::HI ? lane : G::HI - 1);
 #pragma unroll
     for (int q = 0; q < W / 4; ++q) {
       const float4 t = *reinterpret_cast<const float4 *>(buf + y * G::RS + 4 * q);
-      in[4 * q + 0] = t.x; in[4 * q + 1] = t.y; in[4 * q + 2] = t.z; in[4 * q + 3] = t.w;
+      in[2 * q] = (f32x2){t.x, t.y};
+      in[2 * q + 1] = (f32x2){t.z, t.w};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the whole wave has its rows: this round's raw rows are free
     float *tb = buf + ri * G::SEG;
-#pragma unroll
-    for (int x = 0; x < W; ++x) {
-      float a = 0.f;
-#pragma unroll
-      for (int j = 0; j < T; ++j) a = fmaf(w[j], in[reflect_c(x - R + j, W)], a);
-      if (lane < G::HI) tb[x * G::TS + lane] = a;
-    }
+    // lanes beyond the round's rows hold a copy of its last row and write that row's values again: harmless, and
+    // it keeps the stores free of per-output branches
+    const int yl = lane < G::HI ? lane : G::HI - 1;
+    pass_pairs<W / 2, R>(in, w2, [&](int x, float a) __attribute__((always_inline)) { tb[x * G::TS + yl] = a; });
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // transposed intermediate is in LDS
   float lm = -__builtin_inff();
 #pragma unroll
   for (int ci = 0; ci < G::NCI; ++ci) {
-    float col[H];
+    f32x2 col[H / 2];
     const bool act = lane < G::WI;
     const int x = ci * G::WI + (act ? lane : G::WI - 1);
 #pragma unroll
@@ -789,28 +827,24 @@ __device__ __forceinline__ float wave_passes(float *__restrict__ buf, const doub
 #pragma unroll
         for (int q = 0; q < G::HI / 4; ++q) {
           const float4 t = *reinterpret_cast<const float4 *>(tp + 4 * q);
-          col[ri * G::HI + 4 * q + 0] = t.x; col[ri * G::HI + 4 * q + 1] = t.y;
-          col[ri * G::HI + 4 * q + 2] = t.z; col[ri * G::HI + 4 * q + 3] = t.w;
+          col[ri * G::HI / 2 + 2 * q] = (f32x2){t.x, t.y};
+          col[ri * G::HI / 2 + 2 * q + 1] = (f32x2){t.z, t.w};
         }
       } else {
 #pragma unroll
         for (int q = 0; q < G::HI / 2; ++q) {
           const float2 t = *reinterpret_cast<const float2 *>(tp + 2 * q);
-          col[ri * G::HI + 2 * q + 0] = t.x; col[ri * G::HI + 2 * q + 1] = t.y;
+          col[ri * G::HI / 2 + q] = (f32x2){t.x, t.y};
         }
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int y = 0; y < H; ++y) {
-      float a = 0.f;
-#pragma unroll
-      for (int j = 0; j < T; ++j) a = fmaf(w[j], col[reflect_c(y - R + j, H)], a);
-      if (act) {
-        buf[(y / G::HI) * G::SEG + x * G::TS + (y % G::HI)] = a;       // back over the column it came from
-        lm = fmaxf(lm, a);
-      }
-    }
+    float lmc = -__builtin_inff();
+    pass_pairs<H / 2, R>(col, w2, [&](int y, float a) __attribute__((always_inline)) {
+      buf[(y / G::HI) * G::SEG + x * G::TS + (y % G::HI)] = a;         // back over the column it came from (lanes
+      lmc = fmaxf(lmc, a);                                             // without a column repeat the last one)
+    });
+    if (act) lm = fmaxf(lm, lmc);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   return lm;
