@@ -70,10 +70,10 @@ def pmc_traffic():
     n = b = 0
     dec = None
     for name, v in k.items():
-        if "gemm_kernel" in name:
+        if "gemm_kernel" in name or "gemm_persist_kernel" in name or "gemm_duo_kernel" in name:
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
-        if "decode_lds_kernel" in name:
+        if "pp::decode_" in name and "pass_kernel" not in name and "argmax" not in name:
             dec = v["hbm_bytes_per_launch"]
     return (b / n if n else None), dec, os.path.basename(files[-1])
 
@@ -95,6 +95,55 @@ def measured_peaks():
         return None
     return {"mfma_bf16_random_tflops": round(sum(mf) / len(mf), 0), "hbm_read_gbps": float(rd.group(1)),
             "hbm_write_gbps": float(wr.group(1)), "source": os.path.basename(files[-1])}
+
+
+def decode_at_scale(codec, K, H4, W4, device, iters: int = 20):
+    """The decode kernel alone on a batch large enough to fill the chip for many rounds (B = 1024 at K = 17, 128 at
+    K = 133: the sizes VERDICT r01 item 4 names), synthetic peaked heatmaps resident in HBM, HIP events on the launch
+    stream.  The bs-64 step's own decode (roofline_decode) is one partial round of the chip: a latency, not a rate."""
+    B = 1024 if K <= 32 else 128
+    g = torch.Generator(device=device).manual_seed(4321)
+    yy = torch.arange(H4, device=device, dtype=torch.float32)[None, None, :, None]
+    xx = torch.arange(W4, device=device, dtype=torch.float32)[None, None, None, :]
+    cx = torch.rand((B, K, 1, 1), device=device, generator=g) * (W4 - 1)
+    cy = torch.rand((B, K, 1, 1), device=device, generator=g) * (H4 - 1)
+    sg = 1 + 2 * torch.rand((B, K, 1, 1), device=device, generator=g)
+    amp = 0.3 + 0.7 * torch.rand((B, K, 1, 1), device=device, generator=g)
+    hm = amp * torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
+    hm = (hm + 0.02 * torch.rand(hm.shape, device=device, generator=g)).clamp_(0, 1).contiguous()
+    # the bare C entry point on preallocated outputs (Codec.decode_device's per-call allocations and Python time would
+    # otherwise show up in a 100 us launch)
+    from probpose_pytorch_amd import _lib
+    from probpose_pytorch_amd.heatmap import oks_tap_table
+    L = _lib.lib()
+    taps, radius = oks_tap_table(K, H4, W4, sigmas_for(K))
+    taps, radius = torch.from_numpy(taps).to(device), torch.from_numpy(radius).to(device)
+    kpts = torch.empty((B, K, 2), dtype=torch.float64, device=device)
+    scores = torch.empty((B, K), dtype=torch.float32, device=device)
+    locs = torch.empty((B, K, 2), dtype=torch.float32, device=device)
+    ws = torch.empty((max(int(L.pp_decode_workspace_bytes(B, K, H4, W4)), 4),), dtype=torch.uint8, device=device)
+    stream = _lib.stream_ptr()
+
+    def call():
+        rc = L.pp_decode_f32(_lib.ptr(hm), None, None, None, None, B, K, H4, W4, _lib.ptr(taps), _lib.ptr(radius),
+                             float(W4 - 1), float(H4 - 1), float(4 * W4), float(4 * H4), _lib.ptr(kpts), _lib.ptr(scores),
+                             _lib.ptr(locs), None, None, None, None, _lib.ptr(ws), stream)
+        _lib.check(rc, "pp_decode_f32")
+
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        call()
+    e.record()
+    torch.cuda.synchronize()
+    t = s.elapsed_time(e) * 1e-3 / iters
+    nbytes = float(B * K * (H4 * W4 * 4 + 16 + 28))
+    return {"bound": "hbm", "workload": f"{B} crops x {K} maps of {H4}x{W4}", "achieved": round(nbytes / t / 1e9, 1),
+            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / t / 1e9 / PEAK_HBM_GBPS, 4),
+            "us_per_launch": round(t * 1e6, 1), "bytes_per_launch": nbytes}
 
 
 def sigmas_for(K: int) -> np.ndarray:
@@ -367,14 +416,16 @@ def main():
                        "gflop_per_crop": round(flops_per_crop(cfg) / 1e9, 2)},
             "decode_ms": round(d_t * 1e3, 4),
             "model_tflops": round(flops_per_crop(cfg) * crops_per_s / world / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (+ pp::gemm_persist_kernel where selected)", "achieved": round(achieved, 2), "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (tile forms 2-10) / pp::gemm_duo_kernel (14), whichever the tuner picked per shape", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": g_traffic,
                          "traffic_source": traffic_src, "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
                          "flop_per_launch": round(g_flops / max(g_n, 1), 0)},
-            "roofline_decode": {"bound": "hbm", "kernel": "pp::decode_lds_kernel",
+            "roofline_decode": {"bound": "hbm", "kernel": "pp::decode_wave_kernel" if (H // 4, W // 4) in ((64, 48), (96, 72))
+                                else "pp::decode_lds_kernel / pp::decode_screen_kernel",
                                 "achieved": round(d_bytes / d_t / 1e9, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                 "frac": round(d_bytes / d_t / 1e9 / PEAK_HBM_GBPS, 4), "traffic": d_traffic,
                                 "bytes_per_launch": d_bytes},
+            "roofline_decode_at_scale": decode_at_scale(codec, cfg["K"], H // 4, W // 4, device),
             "attention": {"achieved_tflops": round(a_flops / a_t / 1e12, 2), "ms_per_step": round(a_t * 1e3, 3)},
             "kernel_ms_per_step": {k: round(v[2] * 1e3, 3) for k, v in per_step.items()},
             "gemm_tiles_autotuned": tiles,

@@ -85,7 +85,9 @@ int pp_device_ok(void);
  * (prob,vis,oks passthrough), err f64 [B,K] (= err / sqrt(H^2+W^2)),
  * conv f32 [B,K,H,W] (return_heatmap=True), packed f64 [B,K,7] = (kpt x, kpt y,
  * score, prob, vis, oks, err) per keypoint: the record the multi-GPU all-gather ships.
- * workspace: pp_decode_workspace_bytes() bytes (0 when the map fits in LDS).
+ * workspace: pp_decode_workspace_bytes() bytes, 4-byte aligned: a (B*K + 1)-int hand-over list for 64x48 / 96x72 maps
+ * (the fast path; NULL selects the workgroup-per-map kernels instead), 0 for other maps that fit in LDS, a float64 +
+ * float32 image of the batch for maps that do not.
  * ---------------------------------------------------------------------- */
 size_t pp_decode_workspace_bytes(int B, int K, int H, int W);
 int pp_decode_f32(const float *heatmaps, const float *prob, const float *vis,
@@ -140,7 +142,14 @@ typedef struct pp_gemm_args {
   int tile;                     /* 0 = auto (fewest rounds of resident workgroups), 1 = 128x128,
                                    2 = 192x96 (4 waves, 2 LDS stages), 3 = 192x192, 4 = 192x128 (8 waves, 3 stages), 5 = 384x128 (8 waves, 2 stages),
                                    6 = 192x192 wave-specialised (8 MFMA + 4 DMA waves, 3 stages),
-                                   7 = 192x384, 8 = 256x256, 9 = 192x256 (8 waves, 2 stages; bf16) */
+                                   7 = 192x384, 8 = 256x256, 9 = 192x256 (8 waves, 2 stages; bf16),
+                                   10 = 192x192 with the two wave quartets half a K-tile apart (one loads fragments and
+                                   issues DMA while the other runs MFMAs; bf16 / fp8 plain layers),
+                                   14 = 192x192 as TWO 4-wave workgroups per CU (96x96 wave tiles, 32-deep K-tiles, 72 KB
+                                   of LDS each; plain bf16 layers with bias / GELU / ReLU / f32 residual).
+                                   11-13 are kept-for-the-record experimental forms: 11 = 2x2 MFMA
+                                   waves + 4 DMA waves, 12 = hand-pipelined consumer (lab builds only), 13 = persistent
+                                   workgroups streaming several tiles with a deferred epilogue (bf16 outputs). */
   float out_scale;              /* PP_EPI_OUT_FP8: 1 / (scale of the fp8 output tensor) */
   int splitk;                   /* 0 / 1 = off.  S > 1: the launch computes S partial products per batch entry, split s
                                    over the K range [s * Kd, (s + 1) * Kd) (Kd = the PER-SPLIT depth): operands advance

@@ -280,20 +280,17 @@ __device__ __forceinline__ void conv_passes(const float *__restrict__ rawp, int 
   }
 }
 
-__global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
-    const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks,
-    const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
+__device__ __forceinline__ void decode_lds_map(
+    const int map, char *smem, Best *red, const float *__restrict__ heatmaps, const float *prob, const float *vis,
+    const float *oks, const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
     const int *__restrict__ radius, double den_x, double den_y, double in_w, double in_h,
     DecodeOut o, float *__restrict__ out_conv) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = H * W;
   const int WP = 4 * ((W + 3) >> 2) + 2 * DEC_HALO;              // padded row: [halo | W (+pad to 4) | halo]
   double *tmp = reinterpret_cast<double *>(smem);               // [HW] f64 row-pass result
   float *rawp = reinterpret_cast<float *>(smem + (size_t)HW * 8);  // [H][WP] f32 raw map + reflected halo
   float *buf = rawp;                                             // [HW] f32 convolved map (raw is dead by then)
-  __shared__ Best red[DEC_THREADS / 64];
 
-  const int map = blockIdx.x;
   const int k = map % K;
   const float *__restrict__ src = heatmaps + (size_t)map * HW;
   const int tid = threadIdx.x;
@@ -381,6 +378,34 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
     }
   }
 #endif
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
+    const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks,
+    const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
+    const int *__restrict__ radius, double den_x, double den_y, double in_w, double in_h,
+    DecodeOut o, float *__restrict__ out_conv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ Best red[DEC_THREADS / 64];
+  decode_lds_map(blockIdx.x, smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w,
+                 in_h, o, out_conv);
+}
+
+// The same all-pixel float64 decode over a LIST of maps written by an earlier kernel of the stream (the wave-per-map
+// kernel hands over the maps its float32 screen cannot settle cheaply): list[0] = count, list[1 ..] = map indices.
+// The grid is fixed (graph-capturable); workgroups stride over the list and leave at once when it is empty.
+__global__ __launch_bounds__(DEC_THREADS) void decode_lds_list_kernel(
+    const int *__restrict__ list, const float *__restrict__ heatmaps, const float *prob, const float *vis,
+    const float *oks, const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
+    const int *__restrict__ radius, double den_x, double den_y, double in_w, double in_h, DecodeOut o) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ Best red[DEC_THREADS / 64];
+  const int n = list[0];
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    decode_lds_map(list[1 + b], smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w,
+                   in_h, o, nullptr);
+    __syncthreads();                     // the next map reuses the LDS image and the reduction slots
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -724,10 +749,13 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 //      candidates -> exact float64 value of each candidate by T lanes (one row chain each, the map re-read from L2) +
 //      the column chain; then the four neighbours of the winner in one more round of 3T + 2 row chains; finalize()
 //      on lane 0.
-// Non-finite maps and flat maps with more than DWV_MAXCAND candidates take the float64 chains at every pixel (one
-// pixel per lane per step): slow, rare, exact.
+// Non-finite maps and flat maps (clamped plateaus: more than DWV_MAXCAND candidates) are not settled here: the wave
+// appends the map to a list in the workspace and the all-pixel float64 kernel (decode_lds_list_kernel) that follows
+// on the stream decodes exactly those maps.  (A wave-local exact path for them -- row chains shared through an LDS ring
+// -- was built and measured at 150 us per 64-crop batch of random-weight heatmaps against 24 us for this hand-over:
+// one wave's float64 chains are latency-bound and its register file is too small to interleave enough of them.)
 // ---------------------------------------------------------------------------
-constexpr int DWV_MAXCAND = 64;
+constexpr int DWV_MAXCAND = 8;           // more candidates than this: the map goes to the all-pixel kernel's list
 
 constexpr __host__ __device__ int reflect_c(int i, int n) { return i < 0 ? -i - 1 : (i >= n ? 2 * n - 1 - i : i); }
 
@@ -743,7 +771,6 @@ template <int H_, int W_> struct WaveGeom {
   static constexpr int NLD = HW / 256;                           // 16-byte loads per lane
   static_assert(H % NRI == 0 && W % NCI == 0 && W % 4 == 0 && HI % 4 == 0 && HW % 256 == 0, "wave-per-map geometry");
   static_assert(W * TS <= SEG, "a round's transposed image fits over the raw rows it replaces");
-  static_assert(BUF >= DWV_MAXCAND + 2 * 64 + 16, "candidate list and chain scratch reuse the buffer");
   static_assert(H <= 128 && W <= 128, "two rounds at most are meant");
 };
 
@@ -850,20 +877,29 @@ __device__ __forceinline__ float wave_passes(float *__restrict__ buf, const doub
   return lm;
 }
 
-// one float64 row chain of the reference's separable evaluation, read from global (L2-hot) memory
-__device__ __forceinline__ double dwv_row_chain(const float *__restrict__ src, int H, int W, int R,
-                                                const double *__restrict__ wk, int yy, int x) {
+// one float64 row chain of the reference's separable evaluation, read from global (L2-hot) memory.  The taps sit in
+// registers and the loop is unrolled to the largest kernel with a uniform guard, so that the loads are issued together
+// and only the FMAs form the chain (a runtime-length loop over taps in memory costs a round trip per step).
+__device__ __forceinline__ double dwv_row_chain(const float *__restrict__ src, int H, int W, int R, int T,
+                                                const double (&wkr)[PP_MAX_TAPS], int yy, int x) {
   const float *rp = src + reflect_once(yy, H) * W;
+  float v[PP_MAX_TAPS];
+#pragma unroll
+  for (int i = 0; i < PP_MAX_TAPS; ++i) v[i] = rp[reflect_once(x - R + (i < T ? i : 0), W)];   // no branch: the loads batch
   double t = 0.0;
-  for (int i = 0; i <= 2 * R; ++i) t = fma(wk[i], (double)rp[reflect_once(x - R + i, W)], t);
+#pragma unroll
+  for (int i = 0; i < PP_MAX_TAPS; ++i) {
+    const double tn = fma(wkr[i], (double)v[i], t);
+    t = i < T ? tn : t;                                   // steps beyond the kernel are computed and dropped
+  }
   return t;
 }
 
 template <int H, int W, int NWV>
-__global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
+__global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel(
     const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
     int K, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y, double in_w,
-    double in_h, DecodeOut o) {
+    double in_h, DecodeOut o, int *__restrict__ slow_list) {
   using G = WaveGeom<H, W>;
   constexpr int HW = G::HW;
   __shared__ __attribute__((aligned(16))) float lds[NWV][G::BUF];
@@ -876,6 +912,13 @@ __global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
   const int r = __builtin_amdgcn_readfirstlane(radius[k]);
   const double *__restrict__ wk = taps + (size_t)k * PP_MAX_TAPS;
 
+#ifdef PP_DWV_STAMPS
+  unsigned long long st[8];
+#define DWS(i_) st[i_] = __builtin_amdgcn_s_memtime()
+#else
+#define DWS(i_)
+#endif
+  DWS(0);
   // 1. HBM -> LDS (row stride RS), A = max |x| (NaN / inf make the map "not finite")
   float amax = 0.f, vmin = __builtin_inff(), vmax = -__builtin_inff();
   bool bad = false;
@@ -913,6 +956,7 @@ __global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the map is in LDS (this wave's own buffer)
 
+  DWS(1);
   int cand_r[(DWV_MAXCAND + 63) / 64];                       // candidate ci lives in lane ci % 64 (register, not LDS:
   cand_r[0] = 0;                                             // the buffer still holds the convolved map while they are found)
   int ncand = DWV_MAXCAND + 1;                               // "every pixel" unless the screen says less
@@ -930,6 +974,7 @@ __global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
     }
     const float m32 = wave_max(lm);
     const float thr = m32 - 128.0f * 5.9604645e-08f * A;     // see the error budget of the screened path above
+    DWS(2);
     // columns whose maximum reaches the threshold (usually one) are scanned by the whole wave, one row per lane.
     // A lane holds the maximum over its NCI columns, so every column of a flagged lane is scanned.
     ncand = 0;
@@ -965,71 +1010,70 @@ __global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
     }
   }
 
-  // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN).  The buffer is free from here on.
-  double *scratch = reinterpret_cast<double *>(buf);         // [64] row-chain results
+  DWS(3);
+  if (ncand > DWV_MAXCAND) {
+    // Flat map (a clamped plateau: hundreds of exact ties and near-ties) or non-finite map (every pixel counts): not
+    // worth a wave's serial chains.  It goes on the list of the all-pixel float64 kernel that follows on the stream.
+    if (lane == 0) slow_list[1 + atomicAdd(slow_list, 1)] = map;
+    return;
+  }
+  // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN).  Row chains on lanes 0..T-1, handed to the
+  // column chain by lane shuffles (no LDS: the buffer still holds the screened map).
   const int T = 2 * r + 1;
+  double wkr[PP_MAX_TAPS];
+#pragma unroll
+  for (int j = 0; j < PP_MAX_TAPS; ++j) wkr[j] = wk[j];
+  auto exact_at = [&](int y, int x) __attribute__((always_inline)) {
+    double t = 0.0;
+    if (lane < T) t = dwv_row_chain(src, H, W, r, T, wkr, y - r + lane, x);
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < PP_MAX_TAPS; ++j) {
+      const double cn = fma(wkr[j], __shfl(t, j, 64), c);
+      c = j < T ? cn : c;
+    }
+    return (float)c;                       // the same number on every lane
+  };
   Best best;
   best.v = -__builtin_inff();
   best.i = 0x7fffffff;
   bool have = false;
+  auto consider = [&](int p, float cv) __attribute__((always_inline)) {
+    if (!have || better(cv, p, best.v, best.i)) {
+      best.v = cv;
+      best.i = p;
+      have = true;
+    }
+  };
   if (ncand <= DWV_MAXCAND) {
     for (int ci = 0; ci < ncand; ++ci) {
-      const int p = __shfl(cand_r[0], ci, 64), y = p / W, x = p - y * W;
-      if (lane < T) scratch[lane] = dwv_row_chain(src, H, W, r, wk, y - r + lane, x);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      double c = 0.0;
-      for (int j = 0; j < T; ++j) c = fma(wk[j], scratch[j], c);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const float cv = (float)c;
-      if (!have || better(cv, p, best.v, best.i)) {
-        best.v = cv;
-        best.i = p;
-        have = true;
-      }
-    }
-  } else {
-    // every pixel, one per lane per step: the same two chains, run by one lane
-    for (int p = lane; p < HW; p += 64) {
-      const int y = p / W, x = p - y * W;
-      double c = 0.0;
-      for (int j = 0; j < T; ++j) c = fma(wk[j], dwv_row_chain(src, H, W, r, wk, y - r + j, x), c);
-      const float cv = (float)c;
-      if (!have || better(cv, p, best.v, best.i)) {
-        best.v = cv;
-        best.i = p;
-        have = true;
-      }
-    }
-#pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) {
-      const float ov = __shfl_xor(best.v, o_, 64);
-      const int oi = __shfl_xor(best.i, o_, 64);
-      if (better(ov, oi, best.v, best.i)) {
-        best.v = ov;
-        best.i = oi;
-      }
+      const int p = __shfl(cand_r[0], ci, 64);
+      consider(p, exact_at(p / W, p % W));
     }
   }
+  DWS(4);
   // exact neighbours of the winner (interior only): lanes [0, T) column x + 1, [T, 2T) column x - 1, [2T, 3T + 2)
   // column x over rows y - 1 - r .. y + 1 + r; then four column chains on lanes 0..3
   const int bx = best.i % W, by = best.i / W;
   const bool interior = bx > 0 && bx < W - 1 && by > 0 && by < H - 1;
   float nb = 0.f;                 // lane q < 4: value at (x + 1), (x - 1), (y + 1), (y - 1)
   if (interior) {
+    double t = 0.0;
     if (lane < 3 * T + 2) {
       const int grp = lane < T ? 0 : (lane < 2 * T ? 1 : 2);
       const int idx = lane - grp * T;
       const int xx = grp == 0 ? bx + 1 : (grp == 1 ? bx - 1 : bx);
       const int yy = grp == 2 ? by - 1 - r + idx : by - r + idx;
-      scratch[lane] = dwv_row_chain(src, H, W, r, wk, yy, xx);
+      t = dwv_row_chain(src, H, W, r, T, wkr, yy, xx);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane < 4) {
-      const int base = lane == 0 ? 0 : (lane == 1 ? T : (lane == 2 ? 2 * T + 2 : 2 * T));
-      double c = 0.0;
-      for (int j = 0; j < T; ++j) c = fma(wk[j], scratch[base + j], c);
-      nb = (float)c;
+    const int base = lane == 0 ? 0 : (lane == 1 ? T : (lane == 2 ? 2 * T + 2 : 2 * T));
+    double c = 0.0;
+#pragma unroll
+    for (int j = 0; j < PP_MAX_TAPS; ++j) {
+      const double cn = fma(wkr[j], __shfl(t, (base + j) & 63, 64), c);  // lanes >= 4: unused values
+      c = j < T ? cn : c;
     }
+    nb = (float)c;
   }
   const float n_xp = __shfl(nb, 0, 64), n_xm = __shfl(nb, 1, 64), n_yp = __shfl(nb, 2, 64), n_ym = __shfl(nb, 3, 64);
   if (lane == 0) {
@@ -1038,6 +1082,15 @@ __global__ __launch_bounds__(NWV * 64, 3) void decode_wave_kernel(
     };
     finalize(map, B, K, H, W, best.i, at, src, prob, vis, oks, err, den_x, den_y, in_w, in_h, o);
   }
+#ifdef PP_DWV_STAMPS
+  DWS(5);
+  if (lane == 0) {   // diagnostic build: phase cycles behind the locs array (tools/dwv_stamps.py sizes it)
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(o.locs + (size_t)2 * B * K) + (size_t)map * 8;
+    d[0] = st[1] - st[0]; d[1] = st[2] - st[1]; d[2] = st[3] - st[2]; d[3] = st[4] - st[3]; d[4] = st[5] - st[4];
+    d[5] = st[5] - st[0]; d[6] = r; d[7] = ncand;
+  }
+#endif
+#undef DWS
 }
 
 static size_t screen_lds_bytes(int H, int W) {
@@ -1112,6 +1165,7 @@ static size_t lds_bytes(int H, int W) {
   return (size_t)H * W * 8 + (size_t)H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) * 4;
 }
 static bool fits_lds(int H, int W) { return lds_bytes(H, W) <= LDS_LIMIT; }
+static bool wave_geometry(int H, int W) { return (H == 64 && W == 48) || (H == 96 && W == 72); }
 // PP_DECODE_EXACT_ALL=1 forces the all-pixel float64 kernel (A/B runs and the equivalence test of the screened path)
 static bool getenv_flag(const char *name) {
   const char *e = getenv(name);
@@ -1122,6 +1176,7 @@ static bool getenv_exact() { return getenv_flag("PP_DECODE_EXACT_ALL"); }
 }  // namespace pp
 
 extern "C" size_t pp_decode_workspace_bytes(int B, int K, int H, int W) {
+  if (pp::wave_geometry(H, W)) return ((size_t)B * K + 1) * sizeof(int);   // hand-over list of the wave-per-map path
   if (pp::fits_lds(H, W)) return 0;
   return (size_t)B * K * H * W * (sizeof(double) + sizeof(float));
 }
@@ -1147,18 +1202,31 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   // maps 24.3 vs 22.9 us at B = 64 and 236 vs 234 us at B = 1024 (a tie: both forms are bound by the latency of their
   // short barrier-separated phases, not by HBM, LDS or the FMA rate).  The screened form is the default where it
   // wins (maps larger than 4096 pixels); PP_DECODE_SCREEN=1 forces it everywhere, PP_DECODE_EXACT_ALL=1 never.
-  // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288); PP_DECODE_WAVE=0 turns it off (A/B runs)
+  // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288), when the caller passed the workspace
+  // pp_decode_workspace_bytes asks for (without one: the workgroup-per-map kernels below); PP_DECODE_WAVE=0 turns it
+  // off (A/B runs)
   const char *wave_env = getenv("PP_DECODE_WAVE");
   const bool wave_off = wave_env && wave_env[0] == '0';
-  if (!out_conv && !wave_off && !getenv_exact() && ((uintptr_t)heatmaps & 15) == 0 &&
-      ((H == 64 && W == 48) || (H == 96 && W == 72))) {
+  if (!out_conv && !wave_off && !getenv_exact() && workspace && ((uintptr_t)heatmaps & 15) == 0 &&
+      ((uintptr_t)workspace & 3) == 0 && wave_geometry(H, W)) {
+    int *slow_list = reinterpret_cast<int *>(workspace);       // [0] = count, [1 ..] = maps left to the all-pixel kernel
+    PP_CHECK_HIP(hipMemsetAsync(slow_list, 0, sizeof(int), s));
     if (H == 64)
       hipLaunchKernelGGL((decode_wave_kernel<64, 48, 4>), dim3((unsigned)cdiv(maps, 4)), dim3(256), 0, s, heatmaps, prob,
-                         vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o);
+                         vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, slow_list);
     else
       hipLaunchKernelGGL((decode_wave_kernel<96, 72, 1>), dim3((unsigned)maps), dim3(64), 0, s, heatmaps, prob, vis, oks,
-                         err, B, K, taps, radius, den_x, den_y, in_w, in_h, o);
+                         err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, slow_list);
     PP_CHECK_LAUNCH("decode_wave_kernel");
+    const size_t lds = lds_bytes(H, W);
+    static thread_local unsigned long long attr_mask3 = 0;
+    int dev3 = 0;
+    if (lds > 64 * 1024 && attr_needed(attr_mask3, dev3))
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_lds_list_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    hipLaunchKernelGGL(decode_lds_list_kernel, dim3((unsigned)(maps < 512 ? maps : 512)), dim3(DEC_THREADS), lds, s,
+                       slow_list, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w, in_h, o);
+    PP_CHECK_LAUNCH("decode_lds_list_kernel");
     return 0;
   }
   const bool want_screen = getenv_flag("PP_DECODE_SCREEN") || (long long)H * W > 4096;

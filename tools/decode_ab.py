@@ -25,11 +25,14 @@ for (B, K, H, W, sig) in ((64, 17, 64, 48, orc.COCO17_SIGMAS), (256, 17, 64, 48,
     scores = torch.zeros((B, K), device="cuda")
     locs = torch.zeros((B, K, 2), device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.pp_decode_workspace_bytes.restype = C.c_size_t
+    nws = L.pp_decode_workspace_bytes(B, K, H, W)
+    ws = torch.empty((max(nws, 4),), dtype=torch.uint8, device="cuda")
 
     def call():
         rc = L.pp_decode_f32(hm.data_ptr(), None, None, None, None, B, K, H, W, taps.data_ptr(), radius.data_ptr(),
                              float(W - 1), float(H - 1), float(4 * W), float(4 * H), kpts.data_ptr(), scores.data_ptr(),
-                             locs.data_ptr(), None, None, None, None, None, st)
+                             locs.data_ptr(), None, None, None, None, ws.data_ptr() if nws else None, st)
         assert rc == 0, L.pp_last_error()
 
     res = {}
