@@ -37,7 +37,9 @@ def test_argument_validation_without_gpu(built_lib):
     rc = built_lib.pp_decode_f32(None, None, None, None, None, 1, 17, 64, 48, None, None,
                                  1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, None)
     assert rc != 0 and b"null" in built_lib.pp_last_error()
-    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == 0
+    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == (17 + 1) * 4     # hand-over list of the wave-per-map path
+    assert built_lib.pp_decode_workspace_bytes(2, 133, 96, 72) == (2 * 133 + 1) * 4
+    assert built_lib.pp_decode_workspace_bytes(1, 17, 32, 24) == 0                # fits LDS, no list
     assert built_lib.pp_decode_workspace_bytes(1, 20, 256, 256) == 20 * 256 * 256 * 12
     with pytest.raises(_lib.HipExtensionError):
         _lib.check(rc, "pp_decode_f32")
