@@ -99,18 +99,23 @@ def measured_peaks():
 
 def decode_at_scale(codec, K, H4, W4, device, iters: int = 20):
     """The decode kernel alone on a batch large enough to fill the chip for many rounds (B = 1024 at K = 17, 128 at
-    K = 133: the sizes VERDICT r01 item 4 names), synthetic peaked heatmaps resident in HBM, HIP events on the launch
-    stream.  The bs-64 step's own decode (roofline_decode) is one partial round of the chip: a latency, not a rate."""
+    K = 133: the sizes VERDICT r01 item 4 names), synthetic peaked heatmaps resident in HBM (the recipe of
+    oracle.synthetic_heatmaps / tools/decode_ab.py: Gaussian blobs + noise, every 7th peak on a border, every 11th map
+    zero), HIP events on the launch stream.  The bs-64 step's own decode (roofline_decode) is one partial round of the chip: a latency, not a rate."""
     B = 1024 if K <= 32 else 128
     g = torch.Generator(device=device).manual_seed(4321)
     yy = torch.arange(H4, device=device, dtype=torch.float32)[None, None, :, None]
     xx = torch.arange(W4, device=device, dtype=torch.float32)[None, None, None, :]
     cx = torch.rand((B, K, 1, 1), device=device, generator=g) * (W4 - 1)
+    nn_ = torch.arange(B * K, device=device).reshape(B, K, 1, 1)
+    cx = torch.where(nn_ % 7 == 3, torch.where((nn_ // 7) % 2 == 0, 0.0, W4 - 1.0), cx)   # every 7th peak on a border
     cy = torch.rand((B, K, 1, 1), device=device, generator=g) * (H4 - 1)
     sg = 1 + 2 * torch.rand((B, K, 1, 1), device=device, generator=g)
     amp = 0.3 + 0.7 * torch.rand((B, K, 1, 1), device=device, generator=g)
     hm = amp * torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
-    hm = (hm + 0.02 * torch.rand(hm.shape, device=device, generator=g)).clamp_(0, 1).contiguous()
+    hm = (hm + 0.02 * torch.rand(hm.shape, device=device, generator=g)).clamp_(0, 1)
+    n = torch.arange(B * K, device=device).reshape(B, K, 1, 1)
+    hm = torch.where(n % 11 == 5, torch.zeros_like(hm), hm).contiguous()     # every 11th map is an all-zero channel
     # the bare C entry point on preallocated outputs (Codec.decode_device's per-call allocations and Python time would
     # otherwise show up in a 100 us launch)
     from probpose_pytorch_amd import _lib
@@ -269,6 +274,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode-scale", action="store_true", help="skip the decode-at-scale measurement (profiler runs: "
+                    "its launches would be averaged into the step's decode kernel)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (fp32-mode throughput + deviation "
                                                               "of the decoded results from the CPU oracle on 8 crops)")
     ap.add_argument("--single-stream", action="store_true",
@@ -425,7 +432,7 @@ def main():
                                 "achieved": round(d_bytes / d_t / 1e9, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                 "frac": round(d_bytes / d_t / 1e9 / PEAK_HBM_GBPS, 4), "traffic": d_traffic,
                                 "bytes_per_launch": d_bytes},
-            "roofline_decode_at_scale": decode_at_scale(codec, cfg["K"], H // 4, W // 4, device),
+            "roofline_decode_at_scale": None if args.no_decode_scale else decode_at_scale(codec, cfg["K"], H // 4, W // 4, device),
             "attention": {"achieved_tflops": round(a_flops / a_t / 1e12, 2), "ms_per_step": round(a_t * 1e3, 3)},
             "kernel_ms_per_step": {k: round(v[2] * 1e3, 3) for k, v in per_step.items()},
             "gemm_tiles_autotuned": tiles,

@@ -1224,7 +1224,7 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
     if (lds > 64 * 1024 && attr_needed(attr_mask3, dev3))
       PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_lds_list_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    hipLaunchKernelGGL(decode_lds_list_kernel, dim3((unsigned)(maps < 512 ? maps : 512)), dim3(DEC_THREADS), lds, s,
+    hipLaunchKernelGGL(decode_lds_list_kernel, dim3((unsigned)(maps < 256 ? maps : 256)), dim3(DEC_THREADS), lds, s,
                        slow_list, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w, in_h, o);
     PP_CHECK_LAUNCH("decode_lds_list_kernel");
     return 0;

@@ -1929,7 +1929,11 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.tiles_n = cdiv(a->N, bn);
   dim3 grid;
   auto set_grid = [&](int c) {   // c = tile configuration; tiles_m / tiles_n are set
+#ifdef PP_GEMM_RN_WIDE   /* lab: XCD blocks as wide as the whole N (A row-panels cross the fabric once) */
+    const int rn_ = std::min(PP_GEMM_RN_WIDE, p.tiles_n);
+#else
     const int rn_ = std::min((c >= 3) ? 4 : 8, p.tiles_n);
+#endif
     const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
     p.rn = rn_;
     p.blocked = nblk >= 16 ? 1 : 0;
