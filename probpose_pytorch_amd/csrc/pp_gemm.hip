@@ -289,6 +289,13 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + sw * PA * 1024);
     st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + sw * PB * 1024);
     st_koff = (size_t)kt * ROW_BYTES;
+#ifdef PP_GEMM_KROT   /* lab: column tile tn walks K from K-tile (tn * PP_GEMM_KROT) % nkt, so that the workgroups that
+                         share an A row-panel do not ask for the same lines at the same moment */
+    if constexpr (!GATHER) {
+      const int ktr = kt + (tn * PP_GEMM_KROT) % nkt;
+      st_koff = (size_t)(ktr >= nkt ? ktr - nkt : ktr) * ROW_BYTES;
+    }
+#endif
     if constexpr (GATHER) {
       const int k0 = kt * BK;
       const int seg = k0 / p.seg_len;

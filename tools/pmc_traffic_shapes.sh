@@ -3,7 +3,7 @@
 set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-for SHAPE in "qkv 12288 2304 768 3" "proj 12288 768 768 3 resid" "fc1 12288 3072 768 3" "fc1_t9 12288 3072 768 9" "fc2 12288 768 3072 3 resid"; do
+for SHAPE in ${PP_SHAPES:-"qkv 12288 2304 768 3" "proj 12288 768 768 3 resid" "fc1 12288 3072 768 3" "fc1_t9 12288 3072 768 9" "fc2 12288 768 3072 3 resid"}; do
   set -- $SHAPE
   NAME=$1; shift
   M=$1; N=$2; K=$3; T=$4; R=${5:-}
