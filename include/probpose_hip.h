@@ -45,13 +45,9 @@ extern "C" {
 #define PP_EPI_RESIDUAL 8               /* out_f32 = residual_f32 + (acc + bias)      */
 #define PP_EPI_OUT_F32 16               /* store fp32 regardless of the storage dtype */
 #define PP_EPI_ROWBIAS 32               /* + rowbias[(m % rowbias_period) * ldc + n]  (pos_embed) */
-#define PP_EPI_ROWSTATS 128              /* LayerNorm fusion, producer side: besides C (fp32 residual stream) write a
-                                           storage-dtype copy C2 and per-row partial (sum, sum of squares) of the output
-                                           row over this workgroup's column tile into stats_out[m][tile_n][2]        */
-#define PP_EPI_LNFOLD 256                /* LayerNorm fusion, consumer side: A holds the UN-normalised rows x, W holds
-                                           W*diag(gamma), bias holds b + W*beta, colsum[n] = sum_k W'[n,k]; the epilogue
-                                           applies out = rstd_m * (acc - mean_m * colsum[n]) + bias[n] with mean/rstd
-                                           from stats_in (exactly LN(x) W^T + b in exact arithmetic)                */
+#define PP_EPI_ROWSTATS 128              /* RETIRED (refused): round-1 LayerNorm fusion, producer side */
+#define PP_EPI_LNFOLD 256                /* RETIRED (refused): round-1 LayerNorm fusion, consumer side.  The fusion cost
+                                           +11..16 us per fused GEMM against the 12 us LayerNorm launch it replaced. */
 #define PP_EPI_OUT_FP8 512              /* fp8 GEMM only: store e4m3(value * out_scale) instead of bf16 (the next fp8 GEMM's A) */
 #define PP_EPI_NOCLAMP 1024             /* with PP_EPI_HEATMAP: store v / temperature unclamped (the Sparsemax path, head.py:526-528) */
 #define PP_EPI_FUSE_FINAL 2048           /* bf16, N = 256 (tile 9): the epilogue also applies the final 1x1 heatmap layer
@@ -131,14 +127,14 @@ typedef struct pp_gemm_args {
   int epilogue;                 /* PP_EPI_* flags                       */
   int hm_K, hm_HW;              /* PP_EPI_HEATMAP geometry              */
   float hm_temperature;         /* head.py:107 (0.5)                    */
-  void *C2;                     /* PP_EPI_ROWSTATS: [M, ldc2] copy of the output rows in the storage dtype */
+  void *C2;                     /* reserved (retired LayerNorm fusion): must be NULL / 0; kept so the struct layout
+                                   of round 1 binaries and bindings stays valid                          */
   int ldc2;
-  float *stats_out;             /* PP_EPI_ROWSTATS: [M, stats_parts, 2]; stats_parts must equal the number of
-                                   column tiles of this launch (N / 192 for tile 3)                     */
-  const float *stats_in;        /* PP_EPI_LNFOLD: the producer's stats buffer                           */
-  int stats_parts;
-  const float *colsum;          /* PP_EPI_LNFOLD: [N] f32; PP_FP8: [N] f32 column scales (batch stride strideBias) */
-  float ln_eps;
+  float *stats_out;             /* reserved */
+  const float *stats_in;        /* reserved */
+  int stats_parts;              /* reserved */
+  const float *colsum;          /* PP_FP8: [N] f32 column scales (batch stride strideBias)               */
+  float ln_eps;                 /* reserved */
   int tile;                     /* 0 = auto (fewest rounds of resident workgroups), 1 = 128x128,
                                    2 = 192x96 (4 waves, 2 LDS stages), 3 = 192x192, 4 = 192x128 (8 waves, 3 stages), 5 = 384x128 (8 waves, 2 stages),
                                    6 = 192x192 wave-specialised (8 MFMA + 4 DMA waves, 3 stages),

@@ -92,13 +92,6 @@ __device__ __forceinline__ unsigned att_pack_fp8x4(float a, float b, float c, fl
   return (unsigned)w;
 }
 
-// two floats -> packed bf16 pair in ONE instruction (round-to-nearest-even, as f32_to_bf16)
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
 template <int PENDING>
 __device__ __forceinline__ void att_wait_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PENDING) : "memory");

@@ -43,6 +43,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return *reinterpret_cast<bf16_t *>(&h);
 }
 
+// two floats -> one packed bf16 pair by ONE v_cvt_pk_bf16_f32 (the same rounding as f32_to_bf16, which the compiler
+// lowers to that instruction with one live input, a shift and an or around it)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
 template <typename T> struct Store;
 template <> struct Store<float> {
   static __device__ __forceinline__ float ld(const float *p) { return *p; }

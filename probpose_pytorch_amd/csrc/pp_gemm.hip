@@ -87,13 +87,7 @@ struct GemmParams {
   int hm_K, hm_HW;
   float hm_temperature;
   int tiles_m, tiles_n;
-  char *C2;          // PP_EPI_ROWSTATS: storage-dtype copy of the output rows
-  int ldc2;
-  float *stats_out;
-  const float *stats_in;
-  int stats_parts;
   const float *colsum;
-  float ln_eps;
   float out_scale;   // fp8 output: value * out_scale is what gets rounded to e4m3
   int blocked;       // XCD-blocked tile order (large grids) vs plain order
   int rn;            // column tiles per XCD block (<= tiles_n, so narrow-N launches carry no empty slots)
@@ -173,9 +167,6 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // the ragged variant (VEC = false) keeps the element-wise paths.  Both are compile-time so the hot
 // plain-GEMM instantiation carries none of the gather / scalar code or its registers.
 //
-// LN: LayerNorm fusion compiled in (0 none, 1 producer = PP_EPI_ROWSTATS, 2 consumer = PP_EPI_LNFOLD); a
-// template mode so that every other instantiation carries none of its registers.
-//
 // NWP > 0 selects the wave-specialised form: WGM x WGN consumer waves that only read fragments and
 // issue MFMAs, plus NWP producer waves that only issue the LDS-DMA pieces.  A global_load_lds
 // blocks its wave for ~100-200 cycles while the CU's address unit drains (measured); with the DMA
@@ -187,7 +178,7 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // fragment reads and DMA pieces for the next one.  One barrier per K-tile as before; between two barriers each
 // SIMD always has one wave in its matrix segment and the other in its LDS / DMA segment (in the plain form both
 // partners reach their DMA pieces together and the matrix pipe idles while the address unit drains).
-template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0, int LN = 0,
+template <typename T, int BM, int BN, int WGM, int WGN, int STAGES, bool GATHER, bool VEC, int NWP = 0,
           bool PINGPONG = false>
 __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 < 2 ? 2 : (WGM * WGN + NWP + 3) / 4) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -649,15 +640,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     }
   }
 
-  // ---- LayerNorm fold (consumer side): per-row mean / rstd from the producer's partial sums, and the
-  // column sums of W' = W diag(gamma); applied in the epilogue as rstd*(acc - mean*colsum) + bias.
-  float ln_mean[TM], ln_rstd[TM];
-  float4 cs4[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    ln_mean[i] = 0.f;
-    ln_rstd[i] = 1.f;
-  }
+  float4 cs4[TN];     // fp8: per-column dequantisation scales
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (VEC && ES == 1) {   // fp8: per-column dequantisation scale (activation scale x weight-row scale)
@@ -665,30 +648,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
       if (n < p.N) cs4[j] = *reinterpret_cast<const float4 *>(p.colsum + (size_t)z * p.strideBias + n);
-    }
-  }
-  if constexpr (VEC && LN == 2) {
-    if ((epi & PP_EPI_LNFOLD) && !is_producer) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = min(m0 + wm * (BM / WGM) + i * 16 + frow, p.M - 1);
-        float s1 = 0.f, s2 = 0.f;
-        for (int q = 0; q < p.stats_parts; ++q) {
-          const float2 t = *reinterpret_cast<const float2 *>(p.stats_in + ((size_t)m * p.stats_parts + q) * 2);
-          s1 += t.x;
-          s2 += t.y;
-        }
-        const float inv = 1.0f / (float)p.Kd;
-        const float mean = s1 * inv;
-        const float var = fmaxf(s2 * inv - mean * mean, 0.f);
-        ln_mean[i] = mean;
-        ln_rstd[i] = 1.0f / sqrtf(var + p.ln_eps);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
-        if (n < p.N) cs4[j] = *reinterpret_cast<const float4 *>(p.colsum + n);
-      }
     }
   }
 
@@ -974,14 +933,13 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     auto lds_epilogue = [&]<int OES>(std::integral_constant<int, OES>) {
       constexpr int BUDGET = STAGES * STAGE_BYTES;
       constexpr auto fits = [](int np) {
-        return BM * (BN / np * OES + 16) + BM * 4 + (LN == 1 ? BM * WGN * 8 : 0) <= BUDGET && WGN % np == 0;
+        return BM * (BN / np * OES + 16) + BM * 4 <= BUDGET && WGN % np == 0;
       };
       constexpr int NPASS = fits(1) ? 1 : (fits(2) ? 2 : 4);
       static_assert(fits(NPASS), "C tile must fit the staging buffers");
       constexpr int PBN = BN / NPASS;                  // columns per pass
       constexpr int CS = PBN * OES + 16;               // padded row stride: keeps 16-B alignment, spreads banks
       int *rows_lds = reinterpret_cast<int *>(smem + BM * CS);
-      float *stats_lds = reinterpret_cast<float *>(smem + BM * CS + BM * 4);   // [BM][WGN][2]
 #pragma unroll
       for (int pass = 0; pass < NPASS; ++pass) {
         __syncthreads();                             // K-loop reads (pass 0) / previous pass's row stores done
@@ -992,16 +950,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
           if (!mine) break;
           const int lr = wm * (BM / WGM) + i * 16 + frow;
           if (wn_in == 0 && fq == 0) rows_lds[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
-          float rs1 = 0.f, rs2 = 0.f;   // PP_EPI_ROWSTATS: this lane's share of the row sums
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             float v[4];
-            if (LN == 2 && (epi & PP_EPI_LNFOLD)) {
-              v[0] = ln_rstd[i] * (acc[i][j][0] - ln_mean[i] * cs4[j].x) + bias4[j].x;
-              v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
-              v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
-              v[3] = ln_rstd[i] * (acc[i][j][3] - ln_mean[i] * cs4[j].w) + bias4[j].w;
-            } else if constexpr (sizeof(T) == 1) {
+            if constexpr (sizeof(T) == 1) {
               v[0] = fmaf(acc[i][j][0], cs4[j].x, bias4[j].x); v[1] = fmaf(acc[i][j][1], cs4[j].y, bias4[j].y);
               v[2] = fmaf(acc[i][j][2], cs4[j].z, bias4[j].z); v[3] = fmaf(acc[i][j][3], cs4[j].w, bias4[j].w);
             } else {
@@ -1015,13 +967,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {
-              const int n = n0 + wn * (BN / WGN) + j * 16 + fq * 4;
-              if (n < p.N) {   // N % 4 == 0 on this path: the whole quad is in range
-                rs1 += (v[0] + v[1]) + (v[2] + v[3]);
-                rs2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-              }
-            }
             char *dst = smem + lr * CS + (wn_in * (BN / WGN) + j * 16 + fq * 4) * OES;
             if constexpr (OES == 4) {
               *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1030,19 +975,9 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
               *reinterpret_cast<unsigned *>(dst) = pack_fp8x4(v[0] * q, v[1] * q, v[2] * q, v[3] * q);
             } else {
               uint2 pk;
-              pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-              pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              pk.x = pack_bf16x2(v[0], v[1]);
+              pk.y = pack_bf16x2(v[2], v[3]);
               *reinterpret_cast<uint2 *>(dst) = pk;
-            }
-          }
-          if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {   // lanes (frow, fq = 0..3) of a wave share row lr
-            rs1 += __shfl_xor(rs1, 16, 64);
-            rs1 += __shfl_xor(rs1, 32, 64);
-            rs2 += __shfl_xor(rs2, 16, 64);
-            rs2 += __shfl_xor(rs2, 32, 64);
-            if (fq == 0) {
-              stats_lds[(lr * WGN + wn) * 2 + 0] = rs1;
-              stats_lds[(lr * WGN + wn) * 2 + 1] = rs2;
             }
           }
         }
@@ -1105,66 +1040,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
           *reinterpret_cast<uint4 *>(Cb + ((size_t)r * p.ldc + n0 + pass * PBN) * OES + cc * 16) = v;
         }
       }
-      if (LN == 1 && (epi & PP_EPI_ROWSTATS)) {   // one partial (sum, sum of squares) per row for this column tile
-        __syncthreads();
-        for (int lr = tid; lr < BM; lr += NTHREADS_EPI) {
-          if (m0 + lr >= p.M) continue;
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int wq = 0; wq < WGN; ++wq) {
-            s1 += stats_lds[(lr * WGN + wq) * 2 + 0];
-            s2 += stats_lds[(lr * WGN + wq) * 2 + 1];
-          }
-          float *so = p.stats_out + ((size_t)rows_lds[lr] * p.stats_parts + tn) * 2;
-          so[0] = s1;
-          so[1] = s2;
-        }
-      }
-      if constexpr (LN == 1) if ((epi & PP_EPI_ROWSTATS) && p.C2) {
-        // storage-dtype copy of the output rows (the next GEMM's A operand), staged through LDS like C
-        constexpr int ES2 = (int)sizeof(T);
-        constexpr auto fits2 = [](int np) { return BM * (BN / np * ES2 + 16) + BM * 4 <= BUDGET && WGN % np == 0; };
-        constexpr int NP2 = fits2(1) ? 1 : (fits2(2) ? 2 : 4);
-        static_assert(fits2(NP2), "C2 tile must fit the staging buffers");
-        constexpr int PBN2 = BN / NP2, CS2 = PBN2 * ES2 + 16;
-        int *rows2 = reinterpret_cast<int *>(smem + BM * CS2);
-#pragma unroll
-        for (int pass = 0; pass < NP2; ++pass) {
-          __syncthreads();
-          const bool mine = !is_producer && (wn / (WGN / NP2)) == pass;
-          const int wn_in = wn - pass * (WGN / NP2);
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            if (!mine) break;
-            const int lr = wm * (BM / WGM) + i * 16 + frow;
-            if (wn_in == 0 && fq == 0) rows2[lr] = (m0 + lr < p.M) ? out_row[i] : -1;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float v0 = acc[i][j][0] + bias4[j].x, v1 = acc[i][j][1] + bias4[j].y,
-                          v2 = acc[i][j][2] + bias4[j].z, v3 = acc[i][j][3] + bias4[j].w;
-              char *dst = smem + lr * CS2 + (wn_in * (BN / WGN) + j * 16 + fq * 4) * ES2;
-              if constexpr (ES2 == 4) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
-              } else {
-                uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-                pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
-                *reinterpret_cast<uint2 *>(dst) = pk;
-              }
-            }
-          }
-          __syncthreads();
-          constexpr int CPR2 = PBN2 * ES2 / 16;
-          const int ncols16 = max(0, min(CPR2, (p.N - n0 - pass * PBN2) * ES2 / 16));
-          for (int c = tid; c < BM * CPR2; c += NTHREADS_EPI) {
-            const int lr = c / CPR2, cc = c - lr * CPR2;
-            const int r = rows2[lr];
-            if (r < 0 || cc >= ncols16) continue;
-            const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS2 + cc * 16);
-            *reinterpret_cast<uint4 *>(p.C2 + ((size_t)r * p.ldc2 + n0 + pass * PBN2) * ES2 + cc * 16) = v;
-          }
-        }
-      }
     };
     if (p.lds_epilogue) {
       if (sizeof(T) == 4 || (epi & PP_EPI_OUT_F32))
@@ -1187,12 +1062,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
                     acc[i][j][3] + bias4[j].w};
-      if (LN == 2 && (epi & PP_EPI_LNFOLD)) {
-        v[0] = ln_rstd[i] * (acc[i][j][0] - ln_mean[i] * cs4[j].x) + bias4[j].x;
-        v[1] = ln_rstd[i] * (acc[i][j][1] - ln_mean[i] * cs4[j].y) + bias4[j].y;
-        v[2] = ln_rstd[i] * (acc[i][j][2] - ln_mean[i] * cs4[j].z) + bias4[j].z;
-        v[3] = ln_rstd[i] * (acc[i][j][3] - ln_mean[i] * cs4[j].w) + bias4[j].w;
-      }
       if (epi & PP_EPI_GELU) {
         gelu4<T>(v);
       }
@@ -1206,8 +1075,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
           *reinterpret_cast<float4 *>(reinterpret_cast<float *>(Cb) + idx) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 pk;
-          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
           *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(Cb) + idx) = pk;
         }
       } else {
@@ -1461,8 +1330,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
       float v[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
                     __uint_as_float(hi & 0xffff0000u)};
       gelu4<bf16_t>(v);
-      lo = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-      hi = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+      lo = pack_bf16x2(v[0], v[1]);
+      hi = pack_bf16x2(v[2], v[3]);
     }
     if (m < p.M && prev_n0 + nl < p.N) {
       const unsigned long long pk = (unsigned long long)lo | ((unsigned long long)hi << 32);
@@ -1541,8 +1410,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
         if (epi & PP_EPI_RELU) {
           v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
         }
-        fin[i][j] = u32x2{(unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16),
-                          (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16)};
+        fin[i][j] = u32x2{pack_bf16x2(v0, v1),
+                          pack_bf16x2(v2, v3)};
       }
     }
     prev_m0 = tm * BM; prev_n0 = tn * BN; have_prev = true;
@@ -1782,8 +1651,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
               *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
               uint2 pk;
-              pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-              pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+              pk.x = pack_bf16x2(v[0], v[1]);
+              pk.y = pack_bf16x2(v[2], v[3]);
               *reinterpret_cast<uint2 *>(dst) = pk;
             }
           }
@@ -1845,20 +1714,15 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   if (a->epilogue & PP_EPI_RESIDUAL) PP_REQUIRE(a->residual, "pp_gemm: PP_EPI_RESIDUAL without residual");
   if (a->epilogue & PP_EPI_ROWBIAS)
     PP_REQUIRE(a->rowbias && a->rowbias_period > 0, "pp_gemm: PP_EPI_ROWBIAS without rowbias/period");
-  if (a->epilogue & PP_EPI_LNFOLD)
-    PP_REQUIRE(a->stats_in && a->colsum && a->stats_parts > 0 && a->ln_eps > 0.f && !a->rowoff,
-               "pp_gemm: PP_EPI_LNFOLD needs stats_in, colsum, stats_parts, ln_eps and a plain (non-gather) A");
-  if (a->epilogue & PP_EPI_ROWSTATS)
-    PP_REQUIRE(a->stats_out && a->stats_parts > 0 && (!a->C2 || (a->ldc2 % 8 == 0 && ((uintptr_t)a->C2 & 15) == 0 && a->N % 8 == 0)),
-               "pp_gemm: PP_EPI_ROWSTATS needs stats_out / stats_parts (and a 4-aligned ldc2)");
-  PP_REQUIRE(!((a->epilogue & PP_EPI_ROWSTATS) && (a->epilogue & PP_EPI_LNFOLD)),
-             "pp_gemm: a GEMM is either a LayerNorm producer or a consumer");
+  PP_REQUIRE(!(a->epilogue & (PP_EPI_ROWSTATS | PP_EPI_LNFOLD)),
+             "pp_gemm: the LayerNorm-fusion epilogues (PP_EPI_ROWSTATS / PP_EPI_LNFOLD) were removed in round 2: measured "
+             "+11..16 us per fused GEMM against the 12 us LayerNorm launch they replace");
   if (a->epilogue & PP_EPI_HEATMAP)
     PP_REQUIRE(a->hm_K >= a->N && a->hm_HW > 0 && a->hm_temperature != 0.f, "pp_gemm: bad heatmap epilogue");
   if (a->epilogue & PP_EPI_FUSE_FINAL) {
     PP_REQUIRE(a->dtype == PP_BF16 && a->N == 256 && a->final_w && a->final_b && a->hm_K > 0 && a->hm_K <= 32 &&
                    a->hm_HW > 0 && a->hm_temperature != 0.f && (a->tile == 9 || a->tile == 0) &&
-                   !(a->epilogue & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP | PP_EPI_RESIDUAL | PP_EPI_ROWSTATS | PP_EPI_LNFOLD)) &&
+                   !(a->epilogue & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP | PP_EPI_RESIDUAL)) &&
                    ((uintptr_t)a->final_w & 15) == 0,
                "pp_gemm: PP_EPI_FUSE_FINAL serves bf16 layers with N = 256 outputs (tile 9), K <= 32 keypoint maps");
   }
@@ -1887,12 +1751,11 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   }
   p.epilogue = a->epilogue;
   p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; p.hm_temperature = a->hm_temperature;
-  p.C2 = (char *)a->C2; p.ldc2 = a->ldc2; p.stats_out = a->stats_out; p.stats_in = a->stats_in;
-  p.stats_parts = a->stats_parts; p.colsum = a->colsum; p.ln_eps = a->ln_eps;
+  p.colsum = a->colsum;
   p.out_scale = a->out_scale;
   p.final_w = (const char *)a->final_w; p.final_b = a->final_b;
   if (a->dtype == PP_FP8) {
-    PP_REQUIRE(a->colsum && !a->rowoff && !a->out_rowmap && !(a->epilogue & (PP_EPI_ROWSTATS | PP_EPI_LNFOLD | PP_EPI_ROWBIAS | PP_EPI_HEATMAP)),
+    PP_REQUIRE(a->colsum && !a->rowoff && !a->out_rowmap && !(a->epilogue & (PP_EPI_ROWBIAS | PP_EPI_HEATMAP)),
                "pp_gemm: fp8 needs colsum = per-column dequantisation scales and a plain (non-gather, non-fused) GEMM");
     if (a->epilogue & PP_EPI_OUT_FP8)
       PP_REQUIRE(a->out_scale > 0.f && !(a->epilogue & PP_EPI_OUT_F32), "pp_gemm: PP_EPI_OUT_FP8 needs out_scale > 0");
@@ -1955,11 +1818,6 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                          ? 1
                          : 0;
   }
-  if (a->epilogue & (PP_EPI_ROWSTATS | PP_EPI_LNFOLD))
-    PP_REQUIRE(vec && p.lds_epilogue, "pp_gemm: LayerNorm fusion needs the vector / LDS epilogue path (aligned N, ldc, C)");
-  if (a->epilogue & PP_EPI_ROWSTATS)
-    PP_REQUIRE(a->stats_parts == p.tiles_n, "pp_gemm: stats_parts=%d but this launch has %d column tiles",
-               a->stats_parts, p.tiles_n);
   hipStream_t s = (hipStream_t)stream;
   if (cfg == 14) {
     // duo form (gemm_duo_kernel): plain bf16 layers (K a multiple of 64 like every bf16 tile; it stages 32-deep K-tiles)
@@ -2005,25 +1863,24 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_CHECK_LAUNCH("gemm_persist_kernel");
     return 0;
   }
-#define PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_)                         \
+#define PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, PP_)                         \
   do {                                                                                                \
     constexpr int lds = gemm_lds_bytes(BM_, BN_, ST_);                                                \
     static thread_local unsigned long long attr_mask = 0;                                             \
     int dev_ = 0;                                                                                     \
     if (attr_needed(attr_mask, dev_))                                                                 \
       PP_CHECK_HIP(hipFuncSetAttribute(                                                               \
-          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_>), \
+          reinterpret_cast<const void *>(gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, PP_>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, lds));                                          \
-    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, PP_>), grid,     \
+    hipLaunchKernelGGL((gemm_kernel<T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, PP_>), grid,     \
                        dim3(64 * (WGM_ * WGN_ + NWP_)), lds, s, p);                                   \
   } while (0)
-#define PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_) PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, LN_, false)
 #define PP_LAUNCH_GEMM_PP(T, BM_, BN_, WGM_, WGN_, ST_)                                               \
   do {                                                                                                \
-    if (gather) PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, true, true, 0, 0, true);               \
-    else PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, false, true, 0, 0, true);                     \
+    if (gather) PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, true, true, 0, true);               \
+    else PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, false, true, 0, true);                     \
   } while (0)
-#define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_) PP_LAUNCH_GEMM_L(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, 0)
+#define PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_) PP_LAUNCH_GEMM_P(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, NWP_, false)
 #define PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_) PP_LAUNCH_GEMM_W(T, BM_, BN_, WGM_, WGN_, ST_, G_, V_, 0)
 #define PP_LAUNCH_GEMM(T, BM_, BN_, WGM_, WGN_, ST_)                                                  \
   do {                                                                                                \
@@ -2031,22 +1888,14 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else PP_LAUNCH_GEMM_V(T, BM_, BN_, WGM_, WGN_, ST_, false, true);                                 \
   } while (0)
   const bool gather = a->rowoff != nullptr;
-  const int ln_mode = (a->epilogue & PP_EPI_ROWSTATS) ? 1 : ((a->epilogue & PP_EPI_LNFOLD) ? 2 : 0);
-  if (ln_mode && a->tile == 0 && !(cfg == 3 || (cfg == 2 && ln_mode == 2))) {
-    // auto-selection landed on a configuration without a LayerNorm-fused instantiation: use tile 3
-    cfg = 3;
-    p.tiles_m = cdiv(a->M, 192);
-    p.tiles_n = cdiv(a->N, 192);
-    set_grid(3);
-  }
 #ifdef PP_GEMM_LAB   // experiment builds (tools/build_lab.sh): only the plain bf16 192x192 forms, compiles in seconds
-  if (a->dtype != PP_BF16 || gather || !vec || ln_mode || !(cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12))
+  if (a->dtype != PP_BF16 || gather || !vec || !(cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12))
     return fail("pp_gemm (lab build): only plain bf16 tiles 3, 6, 10, 11 and 12");
   if (cfg == 3) PP_LAUNCH_GEMM_V(bf16_t, 192, 192, 2, 4, 3, false, true);
   else if (cfg == 6) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
-  else if (cfg == 12) PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 2, 3, false, true, 4, 0, true);
+  else if (cfg == 12) PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 2, 3, false, true, 4, true);
   else if (cfg == 11) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, false, true, 4);
-  else PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 4, 3, false, true, 0, 0, true);
+  else PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 4, 3, false, true, 0, true);
 #else
   if (a->dtype == PP_FP8) {
     PP_REQUIRE(vec && p.lds_epilogue, "pp_gemm: fp8 needs the vector / LDS epilogue path (aligned N, ldc, C)");
@@ -2058,21 +1907,8 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
       set_grid(3);
     }
     if (cfg == 2) PP_LAUNCH_GEMM_V(fp8_t, 192, 96, 2, 2, 2, false, true);
-    else if (cfg == 10) PP_LAUNCH_GEMM_P(fp8_t, 192, 192, 2, 4, 3, false, true, 0, 0, true);
+    else if (cfg == 10) PP_LAUNCH_GEMM_P(fp8_t, 192, 192, 2, 4, 3, false, true, 0, true);
     else PP_LAUNCH_GEMM_V(fp8_t, 192, 192, 2, 4, 3, false, true);
-  } else if (ln_mode) {
-    // LayerNorm-fused instantiations exist for the plain (non-gather) 192x192 tile, and for consumers the 192x96 tile
-    PP_REQUIRE(!gather && vec && (cfg == 3 || (cfg == 2 && ln_mode == 2)),
-               "pp_gemm: LayerNorm fusion is built for tile 3 (and tile 2 on the consumer side), got tile %d", cfg);
-    if (a->dtype == PP_BF16) {
-      if (ln_mode == 1) PP_LAUNCH_GEMM_L(bf16_t, 192, 192, 2, 4, 3, false, true, 0, 1);
-      else if (cfg == 3) PP_LAUNCH_GEMM_L(bf16_t, 192, 192, 2, 4, 3, false, true, 0, 2);
-      else PP_LAUNCH_GEMM_L(bf16_t, 192, 96, 2, 2, 2, false, true, 0, 2);
-    } else {
-      if (ln_mode == 1) PP_LAUNCH_GEMM_L(float, 192, 192, 2, 4, 3, false, true, 0, 1);
-      else if (cfg == 3) PP_LAUNCH_GEMM_L(float, 192, 192, 2, 4, 3, false, true, 0, 2);
-      else PP_LAUNCH_GEMM_L(float, 192, 96, 2, 2, 2, false, true, 0, 2);
-    }
   } else if (!vec) {  // ragged N / heatmap epilogue: element-wise variant, 128x128 only
     if (a->dtype == PP_BF16) {
       if (gather) PP_LAUNCH_GEMM_V(bf16_t, 128, 128, 2, 2, 2, true, false);

@@ -24,12 +24,6 @@ _PLANS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 # so that per-launch event timings are not inflated by the other branch sharing the CUs
 SERIALIZE_HEAD = False
 
-# Optional: bf16 plans can fold every in-block LayerNorm into the neighbouring GEMMs (producer epilogue:
-# bf16 copy of the residual row + per-row partial sums; consumer epilogue: rstd*(acc - mean*colsum) +
-# bias'), which removes 24 of the 25 LayerNorm launches of a ViT-B forward.  Measured on MI355X at bs 64
-# it is a net LOSS (the fused epilogues cost +11..16 us per GEMM, the LayerNorm kernel they replace only
-# 13-15 us at 4.4 TB/s), so it is off by default; fp32 (parity) plans never use it.
-FUSE_LAYERNORM = False
 # Run the ViT blocks of a batch as two half-batch kernel chains on two HIP streams (see VitPlan.forward_tokens).
 # fp8 mode: also run attn.proj on the fp8 MFMA (attention then writes e4m3 with a static per-tensor scale).  Off: on the
 # synthetic ViT-B it buys +2.5 % throughput but moves the decoded keypoints by a median of 4 px against the bf16 path
@@ -125,17 +119,6 @@ class VitPlan:
                     w8, sw = ops.quantize_rows_fp8(lin.weight.detach().to(device))
                     b[name + "_w8"], b[name + "_sw"] = w8, sw
             self.fp8_calibrated = False
-        self.fuse_ln = bool(FUSE_LAYERNORM and not fp8 and dtype == torch.bfloat16 and len(self.blocks) > 0)
-        if self.fuse_ln:
-            for b, blk in zip(self.blocks, vit.blocks):
-                for name, lin, nw, nb in (("qkv", blk.attn.qkv, blk.norm1.weight, blk.norm1.bias),
-                                          ("fc1", blk.mlp.fc1, blk.norm2.weight, blk.norm2.bias)):
-                    w32 = lin.weight.detach().float().to(device)
-                    wg = (w32 * nw.detach().float().to(device)[None, :]).to(dtype).contiguous()
-                    b[name + "_wg"] = wg                                   # W diag(gamma), rounded once
-                    b[name + "_cs"] = wg.float().sum(1).contiguous()       # column sums of the ROUNDED weights
-                    b[name + "_bf"] = (lin.bias.detach().float().to(device) +
-                                       w32 @ nb.detach().float().to(device)).contiguous()
         self.nw = _dev(vit.norm.weight, device, torch.float32)
         self.nb = _dev(vit.norm.bias, device, torch.float32)
         self.neps = vit.norm.eps
@@ -163,9 +146,6 @@ class VitPlan:
         ao = g("ao", (M, C), dt, dev)
         hid = g("hid", (M, self.hidden), dt, dev)
         feats = g("feats", (M, C), dt, dev)
-        if self.fuse_ln:
-            ops.patchify(x, a0, self.patch)
-            return self._forward_tokens_fused(B, M, a0, xres, qkv, ao, hid, feats)
         bufs = (a0, xres, h, qkv, ao, hid, feats)
         if self.fp8:
             if not self.fp8_calibrated:
@@ -285,33 +265,7 @@ def _vit_run_chain_fp8(self, x, B, bufs):
     ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
 
 
-def _vit_forward_tokens_fused(self, B, M, a0, xres, qkv, ao, hid, feats):
-    """bf16 forward with the in-block LayerNorms folded into the GEMM epilogues (see FUSE_LAYERNORM)."""
-    dev, dt, C, N = self.device, self.dtype, self.C, self.N
-    parts = (C + 191) // 192
-    xb = self.ws.get("xb16", (M, C), dt, dev)                       # bf16 copy of the residual stream rows
-    stats = self.ws.get("ln_stats", (M, parts, 2), torch.float32, dev)
-    ops.gemm(a0, self.pe_w, xres, M=M, N=C, Kd=a0.shape[1], lda=a0.shape[1], ldw=a0.shape[1], ldc=C,
-             bias=self.pe_b, rowbias=self.pos, rowbias_period=N, epilogue=EPI_OUT_F32, ln_producer=(xb, stats))
-    last = len(self.blocks) - 1
-    for i, b in enumerate(self.blocks):
-        ops.gemm(xb, b["qkv_wg"], qkv, M=M, N=3 * C, Kd=C, lda=C, ldw=C, ldc=3 * C, bias=b["qkv_bf"],
-                 ln_consumer=(stats, b["qkv_cs"], b["eps1"]))
-        ops.attention(qkv, ao, B, N, self.heads, self.hd)
-        ops.gemm(ao, b["proj_w"], xres, M=M, N=C, Kd=C, lda=C, ldw=C, ldc=C, bias=b["proj_b"], residual=xres,
-                 epilogue=EPI_OUT_F32, ln_producer=(xb, stats))
-        ops.gemm(xb, b["fc1_wg"], hid, M=M, N=self.hidden, Kd=C, lda=C, ldw=C, ldc=self.hidden, bias=b["fc1_bf"],
-                 epilogue=EPI_GELU, ln_consumer=(stats, b["fc1_cs"], b["eps2"]))
-        if i < last:
-            ops.gemm(hid, b["fc2_w"], xres, M=M, N=C, Kd=self.hidden, lda=self.hidden, ldw=self.hidden, ldc=C,
-                     bias=b["fc2_b"], residual=xres, epilogue=EPI_OUT_F32, ln_producer=(xb, stats))
-        else:   # the final norm feeds convolutions (several rows per output): it stays a LayerNorm kernel
-            ops.linear(hid, b["fc2_w"], b["fc2_b"], out=xres, residual=xres)
-    ops.layernorm(xres, self.nw, self.nb, self.neps, feats)
-    return feats
 
-
-VitPlan._forward_tokens_fused = _vit_forward_tokens_fused
 
 
 def _vit_calibrate(self, batches, margin: float = None):

@@ -11,8 +11,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BIAS, EPI_FUSE_FINAL, EPI_GELU, EPI_HEATMAP, EPI_LNFOLD, EPI_NOCLAMP, EPI_OUT_F32, EPI_OUT_FP8, EPI_RELU,  # noqa: F401
-                   EPI_RESIDUAL, EPI_ROWBIAS, EPI_ROWSTATS, PP_BF16, PP_F32, PP_FP8)
+from ._lib import (EPI_BIAS, EPI_FUSE_FINAL, EPI_GELU, EPI_HEATMAP, EPI_NOCLAMP, EPI_OUT_F32, EPI_OUT_FP8, EPI_RELU,  # noqa: F401
+                   EPI_RESIDUAL, EPI_ROWBIAS, PP_BF16, PP_F32, PP_FP8)
 
 FP8 = torch.float8_e4m3fn          # OCP e4m3: what gfx950's fp8 MFMA and conversions use
 FP8_MAX = 448.0
@@ -117,7 +117,7 @@ def _tune(a, key, out, residual):
 def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbias=None,
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
          strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0,
-         ln_producer=None, ln_consumer=None, colscale=None, out_scale=None, splitk=1, strideA_k=0, strideW_k=0,
+         colscale=None, out_scale=None, splitk=1, strideA_k=0, strideW_k=0,
          strideC_k=0, strideRowoff_k=0, fuse_final=None):
     """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h.
     fp8 (A, W torch.float8_e4m3fn): ``colscale`` [N] f32 = activation scale x weight-row scale; ``out`` may be
@@ -149,19 +149,6 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         a.final_w, a.final_b = _p(fw), _p(fb)
         a.hm_K, a.hm_HW, a.hm_temperature = fk, fhw, ftemp
         tile = 9
-    if ln_producer is not None:
-        # LayerNorm fusion, producer: (c2 copy [M, N] in the storage dtype or None, stats [M, parts, 2]);
-        # the 192-wide column tile fixes the number of partials per row
-        c2, stats = ln_producer
-        epilogue |= EPI_ROWSTATS
-        tile = 3
-        a.C2, a.ldc2 = _p(c2), (c2.stride(0) if c2 is not None else 0)
-        a.stats_out, a.stats_parts = _p(stats), stats.shape[1]
-    if ln_consumer is not None:
-        # LayerNorm fusion, consumer: (stats [M, parts, 2], colsum [N], eps)
-        stats, colsum, eps = ln_consumer
-        epilogue |= EPI_LNFOLD
-        a.stats_in, a.stats_parts, a.colsum, a.ln_eps = _p(stats), stats.shape[1], _p(colsum), float(eps)
     if a.dtype == PP_FP8:
         if colscale is None or A.dtype != FP8:
             raise TypeError("fp8 GEMM: A and W must both be float8_e4m3fn and colscale [N] f32 is required")

@@ -183,38 +183,14 @@ def test_gemm_heatmap_epilogue(ops, dtype):
     assert out.min() == 0 and out.max() == 1
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M", [384, 200])
-def test_gemm_layernorm_fusion(ops, dtype, M):
-    """Producer GEMM (fp32 residual update) emits a storage-dtype copy + per-row partial sums; the consumer
-    GEMM on the un-normalised rows with W*diag(gamma) reproduces Linear(LayerNorm(x))."""
-    C, N2 = 768, 1152
-    A = _rand((M, 256), dtype, 1)
-    W1 = _rand((C, 256), dtype, 2, 256 ** -0.5)
-    b1 = _rand((C,), torch.float32, 3)
-    xres = _rand((M, C), torch.float32, 4, 2.0) + 0.3
-    want_x = xres.double() + A.double() @ W1.double().t() + b1.double()
-    parts = (C + 191) // 192
-    stats = torch.full((M, parts, 2), float("nan"), device="cuda")
-    xcopy = torch.empty((M, C), dtype=dtype, device="cuda")
-    ops.gemm(A, W1, xres, M=M, N=C, Kd=256, lda=256, ldw=256, ldc=C, bias=b1, residual=xres,
-             epilogue=ops.EPI_OUT_F32, ln_producer=(xcopy, stats))
-    torch.testing.assert_close(xres.double(), want_x, **_tol(dtype, torch.float32))
-    torch.testing.assert_close(xcopy.double(), want_x, **_tol(dtype, dtype))
-    torch.testing.assert_close(stats[:, :, 0].sum(1).double(), want_x.sum(1), rtol=1e-4, atol=1e-2)
-    torch.testing.assert_close(stats[:, :, 1].sum(1).double(), (want_x ** 2).sum(1), rtol=1e-4, atol=1e-2)
-    # consumer
-    g, beta = _rand((C,), torch.float32, 5) * 0.2 + 1.0, _rand((C,), torch.float32, 6, 0.1)
-    W2 = _rand((N2, C), torch.float32, 7, C ** -0.5)
-    b2 = _rand((N2,), torch.float32, 8)
-    W2g = (W2 * g[None, :]).to(dtype)
-    colsum = W2g.float().sum(1)
-    b2f = b2 + W2 @ beta
-    out = torch.empty((M, N2), dtype=dtype, device="cuda")
-    ops.gemm(xcopy, W2g, out, M=M, N=N2, Kd=C, lda=C, ldw=C, ldc=N2, bias=b2f, ln_consumer=(stats, colsum, 1e-6))
-    ref = F.layer_norm(want_x, (C,), g.double(), beta.double(), 1e-6) @ W2.double().t() + b2.double()
-    tol = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=6e-2)
-    torch.testing.assert_close(out.double(), ref, **tol)
+def test_gemm_retired_layernorm_fusion_flags_are_refused(ops):
+    """The LayerNorm-fusion epilogues of round 1 (flag bits 128 / 256) were removed: the library says so."""
+    from probpose_pytorch_amd import _lib
+    A, W = _rand((192, 64), torch.bfloat16, 1), _rand((192, 64), torch.bfloat16, 2)
+    out = torch.empty((192, 192), dtype=torch.bfloat16, device="cuda")
+    for bit in (128, 256):
+        with pytest.raises(_lib.HipExtensionError, match="removed"):
+            ops.gemm(A, W, out, M=192, N=192, Kd=64, lda=64, ldw=64, ldc=192, epilogue=bit)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
