@@ -930,7 +930,9 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     // and PBN*OES contiguous bytes per row instead of 8/16-B pieces of 16 different rows per
     // wave-instruction (the direct path's store tail cost ~24 % of a K = 768 tile).  Tiles wider than
     // the staging buffers go through in NPASS column passes.  OES = output element size.
-    auto lds_epilogue = [&]<int OES>(std::integral_constant<int, OES>) {
+    // ACT (0 none, 1 GELU, 2 ReLU) is a compile-time mode: with the flag tested per output quad the branches kept
+    // the compiler from interleaving the exp / rcp chains of neighbouring quads (the GELU epilogue is issue-bound)
+    auto lds_epilogue = [&]<int OES, int ACT>(std::integral_constant<int, OES>, std::integral_constant<int, ACT>) {
       constexpr int BUDGET = STAGES * STAGE_BYTES;
       constexpr auto fits = [](int np) {
         return BM * (BN / np * OES + 16) + BM * 4 <= BUDGET && WGN % np == 0;
@@ -960,10 +962,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
               v[0] = acc[i][j][0] + bias4[j].x; v[1] = acc[i][j][1] + bias4[j].y;
               v[2] = acc[i][j][2] + bias4[j].z; v[3] = acc[i][j][3] + bias4[j].w;
             }
-            if (epi & PP_EPI_GELU) {
-              gelu4<T>(v);
-            }
-            if (epi & PP_EPI_RELU) {
+            if constexpr (ACT == 1) gelu4<T>(v);
+            if constexpr (ACT == 2) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
@@ -1042,12 +1042,17 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
       }
     };
     if (p.lds_epilogue) {
+      auto with_act = [&](auto oes) __attribute__((always_inline)) {
+        if (epi & PP_EPI_GELU) lds_epilogue(oes, std::integral_constant<int, 1>{});
+        else if (epi & PP_EPI_RELU) lds_epilogue(oes, std::integral_constant<int, 2>{});
+        else lds_epilogue(oes, std::integral_constant<int, 0>{});
+      };
       if (sizeof(T) == 4 || (epi & PP_EPI_OUT_F32))
-        lds_epilogue(std::integral_constant<int, 4>{});
+        with_act(std::integral_constant<int, 4>{});
       else if (sizeof(T) == 1 && (epi & PP_EPI_OUT_FP8))
-        lds_epilogue(std::integral_constant<int, 1>{});
+        with_act(std::integral_constant<int, 1>{});
       else
-        lds_epilogue(std::integral_constant<int, 2>{});
+        with_act(std::integral_constant<int, 2>{});
       stored = true;
     }
   }
