@@ -192,6 +192,36 @@ def test_full_size_batch_properties(pp):
         np.testing.assert_array_equal(again, kpts)
 
 
+def test_full_size_wave_decode_equals_all_pixel_decode(pp, monkeypatch):
+    """At the sizes the decode rate is quoted on (1024 x 17 x 64x48 and 128 x 133 x 96x72), on DISTINCT device-made maps
+    (blobs + noise, some on borders, some zero, some clamped plateaus): the wave-per-map path and the all-pixel
+    float64 kernel return identical keypoints, scores and locations for every one of the 17 408 / 17 024 maps."""
+    for (B, K, H, W, insz) in ((1024, 17, 64, 48, (192, 256)), (128, 133, 96, 72, (288, 384))):
+        g = torch.Generator(device="cuda").manual_seed(B + K)
+        yy = torch.arange(H, device="cuda", dtype=torch.float32)[None, None, :, None]
+        xx = torch.arange(W, device="cuda", dtype=torch.float32)[None, None, None, :]
+        cx = torch.rand((B, K, 1, 1), device="cuda", generator=g) * (W - 1)
+        cy = torch.rand((B, K, 1, 1), device="cuda", generator=g) * (H - 1)
+        n = torch.arange(B * K, device="cuda").reshape(B, K, 1, 1)
+        cx = torch.where(n % 7 == 3, torch.where((n // 7) % 2 == 0, 0.0, W - 1.0), cx)
+        sg = 1 + 2 * torch.rand((B, K, 1, 1), device="cuda", generator=g)
+        amp = 0.3 + 1.2 * torch.rand((B, K, 1, 1), device="cuda", generator=g)        # > 1: clamped plateaus
+        hm = amp * torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
+        hm = (hm + 0.02 * torch.rand(hm.shape, device="cuda", generator=g)).clamp_(0, 1)
+        hm = torch.where(n % 11 == 5, torch.zeros_like(hm), hm).contiguous()
+        sig = orc.COCO17_SIGMAS if K == 17 else np.random.default_rng(133).uniform(0.02, 0.11, K)
+        probmap = pp.ProbMap(insz, (W, H), sig)
+        for v in ("PP_DECODE_EXACT_ALL", "PP_DECODE_SCREEN", "PP_DECODE_WAVE"):
+            monkeypatch.delenv(v, raising=False)
+        fast = {k: v.cpu().numpy() for k, v in probmap.decode_device(hm).items()}
+        monkeypatch.setenv("PP_DECODE_EXACT_ALL", "1")
+        slow = {k: v.cpu().numpy() for k, v in probmap.decode_device(hm).items()}
+        monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
+        for k in ("kpts", "scores", "locs"):
+            np.testing.assert_array_equal(fast[k], slow[k], err_msg=f"{k} {hm.shape}")
+        assert np.isfinite(fast["kpts"]).all()
+
+
 # ---------------------------------------------------------------------------
 # Target generation (SURVEY.md section 8f rank 3): ProbMap.encode on the GPU vs goldens minted from the reference
 # ---------------------------------------------------------------------------
