@@ -192,6 +192,33 @@ def test_full_size_batch_properties(pp):
         np.testing.assert_array_equal(again, kpts)
 
 
+def test_decode_c_entry_without_workspace_takes_the_workgroup_kernels(pp):
+    """pp_decode_f32 with workspace = NULL on a 64x48 batch (the integration stub of round 1 passed none): no error, the
+    workgroup-per-map kernels run, same numbers as with the hand-over workspace."""
+    import ctypes as C
+    from probpose_pytorch_amd import _lib
+    from probpose_pytorch_amd.heatmap import oks_tap_table
+    L = _lib.lib()
+    B, K, H, W = 5, 17, 64, 48
+    hm = torch.from_numpy(orc.synthetic_heatmaps(B, K, H, W, seed=99, kind="peaked")).cuda()
+    hm[1, 2, 10:40, 5:30] = 1.0                                 # a plateau: goes through the hand-over when there is one
+    taps, radius = oks_tap_table(K, H, W, orc.COCO17_SIGMAS)
+    taps, radius = torch.from_numpy(taps).cuda(), torch.from_numpy(radius).cuda()
+    res = []
+    for with_ws in (True, False):
+        kpts = torch.zeros((B, K, 2), dtype=torch.float64, device="cuda")
+        scores = torch.zeros((B, K), device="cuda")
+        locs = torch.zeros((B, K, 2), device="cuda")
+        ws = torch.empty((int(L.pp_decode_workspace_bytes(B, K, H, W)),), dtype=torch.uint8, device="cuda")
+        rc = L.pp_decode_f32(_lib.ptr(hm), None, None, None, None, B, K, H, W, _lib.ptr(taps), _lib.ptr(radius),
+                             float(W - 1), float(H - 1), 192.0, 256.0, _lib.ptr(kpts), _lib.ptr(scores), _lib.ptr(locs),
+                             None, None, None, None, _lib.ptr(ws) if with_ws else None, _lib.stream_ptr())
+        _lib.check(rc, "pp_decode_f32")
+        res.append((kpts.cpu().numpy(), scores.cpu().numpy(), locs.cpu().numpy()))
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_full_size_wave_decode_equals_all_pixel_decode(pp, monkeypatch):
     """At the sizes the decode rate is quoted on (1024 x 17 x 64x48 and 128 x 133 x 96x72), on DISTINCT device-made maps
     (blobs + noise, some on borders, some zero, some clamped plateaus): the wave-per-map path and the all-pixel
