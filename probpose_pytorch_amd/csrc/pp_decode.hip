@@ -882,19 +882,33 @@ __device__ __forceinline__ float wave_passes(float *__restrict__ buf, const doub
 // one float64 row chain of the reference's separable evaluation, read from global (L2-hot) memory.  The taps sit in
 // registers and the loop is unrolled to the largest kernel with a uniform guard, so that the loads are issued together
 // and only the FMAs form the chain (a runtime-length loop over taps in memory costs a round trip per step).
+// NT: compile-time bound on the taps (7 / 13 / 19: the kernel sizes of radius <= 3 / <= 6 / <= 9), so that a small
+// kernel does not pay for 19 guarded steps.
+template <int NT>
 __device__ __forceinline__ double dwv_row_chain(const float *__restrict__ src, int H, int W, int R, int T,
                                                 const double (&wkr)[PP_MAX_TAPS], int yy, int x) {
   const float *rp = src + reflect_once(yy, H) * W;
-  float v[PP_MAX_TAPS];
+  float v[NT];
 #pragma unroll
-  for (int i = 0; i < PP_MAX_TAPS; ++i) v[i] = rp[reflect_once(x - R + (i < T ? i : 0), W)];   // no branch: the loads batch
+  for (int i = 0; i < NT; ++i) v[i] = rp[reflect_once(x - R + (i < T ? i : 0), W)];   // no branch: the loads batch
   double t = 0.0;
 #pragma unroll
-  for (int i = 0; i < PP_MAX_TAPS; ++i) {
+  for (int i = 0; i < NT; ++i) {
     const double tn = fma(wkr[i], (double)v[i], t);
     t = i < T ? tn : t;                                   // steps beyond the kernel are computed and dropped
   }
   return t;
+}
+// column chain over the row-chain results held by lanes base .. base + T - 1
+template <int NT>
+__device__ __forceinline__ double dwv_col_chain(double t, int base, int T, const double (&wkr)[PP_MAX_TAPS]) {
+  double c = 0.0;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const double cn = fma(wkr[j], __shfl(t, (base + j) & 63, 64), c);
+    c = j < T ? cn : c;
+  }
+  return c;
 }
 
 template <int H, int W, int NWV>
@@ -1026,13 +1040,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
 #pragma unroll
   for (int j = 0; j < PP_MAX_TAPS; ++j) wkr[j] = wk[j];
   auto exact_at = [&](int y, int x) __attribute__((always_inline)) {
-    double t = 0.0;
-    if (lane < T) t = dwv_row_chain(src, H, W, r, T, wkr, y - r + lane, x);
-    double c = 0.0;
-#pragma unroll
-    for (int j = 0; j < PP_MAX_TAPS; ++j) {
-      const double cn = fma(wkr[j], __shfl(t, j, 64), c);
-      c = j < T ? cn : c;
+    double t = 0.0, c;
+    if (T <= 7) {
+      if (lane < T) t = dwv_row_chain<7>(src, H, W, r, T, wkr, y - r + lane, x);
+      c = dwv_col_chain<7>(t, 0, T, wkr);
+    } else if (T <= 13) {
+      if (lane < T) t = dwv_row_chain<13>(src, H, W, r, T, wkr, y - r + lane, x);
+      c = dwv_col_chain<13>(t, 0, T, wkr);
+    } else {
+      if (lane < T) t = dwv_row_chain<PP_MAX_TAPS>(src, H, W, r, T, wkr, y - r + lane, x);
+      c = dwv_col_chain<PP_MAX_TAPS>(t, 0, T, wkr);
     }
     return (float)c;                       // the same number on every lane
   };
@@ -1066,15 +1083,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
       const int idx = lane - grp * T;
       const int xx = grp == 0 ? bx + 1 : (grp == 1 ? bx - 1 : bx);
       const int yy = grp == 2 ? by - 1 - r + idx : by - r + idx;
-      t = dwv_row_chain(src, H, W, r, T, wkr, yy, xx);
+      if (T <= 7) t = dwv_row_chain<7>(src, H, W, r, T, wkr, yy, xx);
+      else if (T <= 13) t = dwv_row_chain<13>(src, H, W, r, T, wkr, yy, xx);
+      else t = dwv_row_chain<PP_MAX_TAPS>(src, H, W, r, T, wkr, yy, xx);
     }
     const int base = lane == 0 ? 0 : (lane == 1 ? T : (lane == 2 ? 2 * T + 2 : 2 * T));
-    double c = 0.0;
-#pragma unroll
-    for (int j = 0; j < PP_MAX_TAPS; ++j) {
-      const double cn = fma(wkr[j], __shfl(t, (base + j) & 63, 64), c);  // lanes >= 4: unused values
-      c = j < T ? cn : c;
-    }
+    const double c = T <= 7 ? dwv_col_chain<7>(t, base, T, wkr)          // lanes >= 4: unused values
+                            : (T <= 13 ? dwv_col_chain<13>(t, base, T, wkr) : dwv_col_chain<PP_MAX_TAPS>(t, base, T, wkr));
     nb = (float)c;
   }
   const float n_xp = __shfl(nb, 0, 64), n_xm = __shfl(nb, 1, 64), n_yp = __shfl(nb, 2, 64), n_ym = __shfl(nb, 3, 64);
