@@ -1069,7 +1069,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
       have = true;
     }
   };
-  if (ncand <= DWV_MAXCAND) {
+  // One candidate (94 % of maps): it IS the arg-max, and its own exact value comes out of the neighbours' round below
+  // (the centre column's row chains are part of it) instead of a round of its own.
+  const bool single = ncand == 1;
+  if (single) {
+    best.i = __shfl(cand_r[0], 0, 64);
+    have = true;
+  } else {
     for (int ci = 0; ci < ncand; ++ci) {
       const int p = __shfl(cand_r[0], ci, 64);
       consider(p, exact_at(p / W, p % W));
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
   }
   DWS(4);
   // exact neighbours of the winner (interior only): lanes [0, T) column x + 1, [T, 2T) column x - 1, [2T, 3T + 2)
-  // column x over rows y - 1 - r .. y + 1 + r; then four column chains on lanes 0..3
+  // column x over rows y - 1 - r .. y + 1 + r; then four (five) column chains on lanes 0..3 (4)
   const int bx = best.i % W, by = best.i / W;
   const bool interior = bx > 0 && bx < W - 1 && by > 0 && by < H - 1;
   float nb = 0.f;                 // lane q < 4: value at (x + 1), (x - 1), (y + 1), (y - 1)
@@ -1092,10 +1098,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
       else if (T <= 13) t = dwv_row_chain<13>(src, H, W, r, T, wkr, yy, xx);
       else t = dwv_row_chain<PP_MAX_TAPS>(src, H, W, r, T, wkr, yy, xx);
     }
-    const int base = lane == 0 ? 0 : (lane == 1 ? T : (lane == 2 ? 2 * T + 2 : 2 * T));
-    const double c = T <= 7 ? dwv_col_chain<7>(t, base, T, wkr)          // lanes >= 4: unused values
+    // lane 4: the centre itself (rows y - r .. y + r of the third group)
+    const int base = lane == 0 ? 0 : (lane == 1 ? T : (lane == 2 ? 2 * T + 2 : (lane == 3 ? 2 * T : 2 * T + 1)));
+    const double c = T <= 7 ? dwv_col_chain<7>(t, base, T, wkr)          // lanes >= 5: unused values
                             : (T <= 13 ? dwv_col_chain<13>(t, base, T, wkr) : dwv_col_chain<PP_MAX_TAPS>(t, base, T, wkr));
     nb = (float)c;
+    if (single) best.v = __shfl(nb, 4, 64);
+  } else if (single) {
+    best.v = exact_at(by, bx);     // border arg-max: no neighbours, the value alone
   }
   const float n_xp = __shfl(nb, 0, 64), n_xm = __shfl(nb, 1, 64), n_yp = __shfl(nb, 2, 64), n_ym = __shfl(nb, 3, 64);
   if (lane == 0) {
