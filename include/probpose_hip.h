@@ -263,6 +263,24 @@ int pp_frontend_crop_resize(const unsigned char *image, int img_w, int img_h, lo
 int pp_encode_probmaps(const float *kpts_hm, const float *visible, const double *two_s, int B, int K, int H,
                        int W, float *heatmaps, float *weights, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Evaluation metric: PCK over a batch of keypoint pairs in one pass.  Replaces the per-instance host code
+ *   _calc_distances        probpose/heatmap.py:55-89   (normalised distances, -1 for masked-out pairs)
+ *   _distance_acc          probpose/heatmap.py:92-111  (fraction below the threshold)
+ *   keypoint_pck_accuracy  probpose/loss.py:825-866    (called from pose_pck_accuracy, loss.py:767-822)
+ * pred / gt [N,K,2] float32 (coord_f64 = 0) or float64 (coord_f64 = 1): the difference is formed in that type;
+ * mask [N,K] u8; norm [N,2] f64 with the reference's "<= 0 -> 1e6" substitution already applied, skip[n] = 1 for an
+ * instance whose normalisation factor held an exact 0 (heatmap.py:78-82); thr: the threshold as the comparison sees it
+ * (a Python float compared with a float32 array is rounded to float32 by numpy 2).  Outputs: counts [2][K] int32 =
+ * (pairs below thr, valid pairs) per keypoint (zeroed here by a memset node), dist [K,N] f32 or NULL.
+ * ---------------------------------------------------------------------- */
+/* get_heatmap_maximum (probpose/heatmap.py:13-52) for `maps` = B*K contiguous H x W float32 maps of any size: locs
+ * [maps,2] f32 = (x, y) of the first maximum in row-major order (a NaN counts as the maximum, like np.argmax),
+ * (-1,-1) where the maximum is <= 0; vals [maps] f32 = the maximum. */
+int pp_heatmap_argmax(const float *heatmaps, long long maps, int H, int W, float *locs, float *vals, void *stream);
+int pp_pck_counts(const void *pred, const void *gt, int coord_f64, const unsigned char *mask, const double *norm,
+                  const unsigned char *skip, double thr, int N, int K, int *counts, float *dist, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -488,3 +488,71 @@ def dark_udp_decode(heatmaps: np.ndarray, blur_kernel_size: int, input_size, hea
         kp[k] -= (hinv @ np.array([dx, dy], dtype=np.float32).reshape(2, 1)).squeeze()
     kpts = kp[None] / [W - 1, H - 1] * input_size
     return kpts, scores[None]
+
+
+# --------------------------------------------------------------------------
+# f3 (second half): evaluation metrics, one instance at a time as the reference evaluates them
+#   compute_oks            probpose/loss.py:715-764
+#   keypoint_pck_accuracy  probpose/loss.py:825-866   (over heatmap.py:55-111)
+#   pose_pck_accuracy      probpose/loss.py:767-822   ('argmax' method)
+# Pinned bit for bit by tests/golden/metrics.npz (minted from the imported reference).  The product's batched forms
+# (probpose_pytorch_amd/metrics.py: oks_batch on arrays, pp_pck_counts on the device) are checked against these and
+# against the goldens.
+# --------------------------------------------------------------------------
+def compute_oks(gt: dict, dt: dict, sigmas: np.ndarray, use_area: bool = True, per_kpt: bool = False):
+    """loss.py:715-764: OKS of one detection against one annotation."""
+    k = len(sigmas)
+    variances = (sigmas * 2) ** 2
+    g = np.array(gt["keypoints"]).reshape(k, 3)
+    d = np.array(dt["keypoints"]).reshape(k, 3)
+    visible = g[:, 2] > 0                                        # loss.py:723-728
+    n_visible = np.count_nonzero(visible)
+    bx, by, bw, bh = gt["bbox"]
+    if n_visible > 0:                                            # loss.py:739-741
+        dx, dy = d[:, 0] - g[:, 0], d[:, 1] - g[:, 1]
+    else:                                                        # loss.py:742-746: distance to the box grown by its size
+        zero = np.zeros(k)
+        dx = np.max((zero, (bx - bw) - d[:, 0]), axis=0) + np.max((zero, d[:, 0] - (bx + bw * 2)), axis=0)
+        dy = np.max((zero, (by - bh) - d[:, 1]), axis=0) + np.max((zero, d[:, 1] - (by + bh * 2)), axis=0)
+    scale = gt["area"] if use_area else bh * bw * 0.53           # loss.py:748-752
+    e = (dx ** 2 + dy ** 2) / variances / (scale + np.spacing(1)) / 2
+    if per_kpt:                                                  # loss.py:754-757
+        oks = np.exp(-e)
+        if n_visible > 0:
+            oks[~visible] = 0
+        return oks
+    if n_visible > 0:                                            # loss.py:759-762
+        e = e[visible]
+    return np.sum(np.exp(-e)) / e.shape[0]
+
+
+def normalized_distances(preds: np.ndarray, gts: np.ndarray, mask: np.ndarray, norm_factor: np.ndarray) -> np.ndarray:
+    """heatmap.py:55-89 -> (K, N) float32, -1 where masked out (``norm_factor`` is edited in place like there)."""
+    N, K, _ = preds.shape
+    use = mask.copy()
+    use[np.where((norm_factor == 0).sum(1))[0], :] = False       # heatmap.py:78-79
+    out = np.full((N, K), -1, dtype=np.float32)
+    norm_factor[np.where(norm_factor <= 0)] = 1e6                # heatmap.py:82
+    out[use] = np.linalg.norm(((preds - gts) / norm_factor[:, None, :])[use], axis=-1)
+    return out.T
+
+
+def keypoint_pck_accuracy(pred, gt, mask, thr, norm_factor):
+    """loss.py:825-866 with heatmap.py:92-111 inlined: per-keypoint accuracy (-1: no valid pair), mean, count."""
+    acc = []
+    for row in normalized_distances(pred, gt, mask, norm_factor):
+        valid = row != -1
+        acc.append((row[valid] < thr).sum() / valid.sum() if valid.sum() > 0 else -1)
+    acc = np.array(acc)
+    good = acc[acc >= 0]
+    return acc, (good.mean() if len(good) > 0 else 0.0), len(good)
+
+
+def pose_pck_accuracy(output: np.ndarray, target: np.ndarray, mask: np.ndarray, thr: float = 0.05, normalize=None):
+    """loss.py:767-822, method 'argmax'."""
+    N, K, H, W = output.shape
+    if K == 0:
+        return None, 0, 0
+    if normalize is None:
+        normalize = np.tile(np.array([[H, W]]), (N, 1))
+    return keypoint_pck_accuracy(get_heatmap_maximum(output)[0], get_heatmap_maximum(target)[0], mask, thr, normalize)

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "pp_tokens_to_nchw": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_nchw_to_tokens": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_encode_probmaps": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pp_heatmap_argmax": (C.c_int, [_vp, C.c_longlong, _i, _i, _vp, _vp, _vp]),
+    "pp_pck_counts": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp]),
     "pp_frontend_plan_bytes": (C.c_longlong, [_i, _vp, _i, _i]),
     "pp_frontend_plan_build": (C.c_int, [_i, _vp, _i, _i, _vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "pp_frontend_crop_resize": (C.c_int, [_vp, _i, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, _i, _i, _vp, _vp]),

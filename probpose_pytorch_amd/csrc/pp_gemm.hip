@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef PP_GEMM_TIMELINE   // diagnostic build: wall-clock (100 MHz) marks per wave + where it ran
   const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
-  unsigned long long rt_loop0 = 0, rt_loop1 = 0;
+  unsigned long long rt_loop0 = 0, rt_loop1 = 0, ct_loop0 = 0, ct_loop1 = 0;   // ct_*: shader cycles (s_memtime)
 #endif
   constexpr int ES = (int)sizeof(T);
   constexpr int BK = ROW_BYTES / ES;  // elements of K per tile
@@ -662,6 +662,11 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
 #ifdef PP_GEMM_STAMPS
   unsigned long long t_pro_v = t_begin;
 #endif
+#ifdef PP_GEMM_TIMELINE
+  rt_loop0 = __builtin_amdgcn_s_memrealtime();
+  ct_loop0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
   if constexpr (NWP > 0 && PINGPONG) {
     // ---- wave-specialised form, software-pipelined consumer (one consumer wave per SIMD: nothing else hides its
     // LDS latency).  MFMA groups of TN (one activation row-tile x all weight column tiles); while group g runs,
@@ -773,6 +778,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
 #endif
 #ifdef PP_GEMM_TIMELINE
   rt_loop0 = __builtin_amdgcn_s_memrealtime();
+  ct_loop0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
   if constexpr (PINGPONG) {
     static_assert(STAGES == 3 && NW == 8, "ping-pong form: 8 waves, 3 LDS stages");
@@ -916,6 +923,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
   PP_STAMP(t_loop);
 #ifdef PP_GEMM_TIMELINE
   rt_loop1 = __builtin_amdgcn_s_memrealtime();
+  ct_loop1 = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- epilogue.  The W fragment is the MFMA "A" operand and the activation fragment the "B"
@@ -1116,7 +1124,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     o[0] = rt_entry; o[1] = rt_loop0; o[2] = rt_loop1; o[3] = rt_end;
     o[4] = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
     o[5] = __builtin_amdgcn_s_getreg(63508);   // HW_REG_XCC_ID
-    o[6] = 1; o[7] = (unsigned long long)tm << 32 | (unsigned)tn;
+    o[6] = ct_loop1 - ct_loop0 + 1;            // K-loop shader cycles (> 0: also the "this wave ran" mark)
+    o[7] = (unsigned long long)tm << 32 | (unsigned)tn;
   }
 #endif
 #ifdef PP_GEMM_STAMPS

@@ -1,13 +1,18 @@
-"""Mirror of the evaluation metrics of the reference (second half):
-``compute_oks`` (loss.py:715-764), ``pose_pck_accuracy`` (loss.py:767-822), ``keypoint_pck_accuracy``
-(loss.py:825-866) and the helpers they use from heatmap.py (``get_heatmap_maximum`` :13-52, ``_calc_distances``
-:55-89, ``_distance_acc`` :92-111).
+"""Evaluation metrics of the reference as BATCHED operations (second half).
 
-The per-instance OKS / PCK arithmetic is K numbers per instance and stays on the host in numpy, exactly as the
-reference evaluates it (pinned bit-for-bit by tests/golden/metrics.npz, minted from the imported reference).  What
-the reference does per heatmap on the host -- the arg-max of every map (``get_heatmap_maximum``) and the
-expected-value decode (``get_heatmap_expected_value``) -- runs in the HIP decode kernels on the whole batch, and only
-B*K*2 coordinates come back.
+The reference evaluates one instance at a time on the host: ``compute_oks`` (loss.py:715-764) for one (annotation,
+detection) pair, ``keypoint_pck_accuracy`` (loss.py:825-866) through a Python loop over keypoints around
+heatmap.py:55-111, ``pose_pck_accuracy`` (loss.py:767-822) after a per-map arg-max (heatmap.py:13-52).  Here:
+
+* ``oks_batch`` -- object keypoint similarity of N pairs at once, array-in / array-out; ``compute_oks`` is the
+  one-pair view of it with the reference's dict interface.  K numbers per instance: float64 array arithmetic on the host
+  (the float64 ``exp`` of a GPU math library is not the host libm's bit for bit, and this metric is pinned bit for bit).
+* ``pck_counts`` / ``keypoint_pck_accuracy`` -- one HIP pass over all N x K pairs (``pp_pck_counts``): per-keypoint hit
+  and valid COUNTS come back as 2 K integers; the accuracies are their quotients.
+* ``pose_pck_accuracy`` -- heatmaps in, accuracy out: both arg-max passes and the counting run on the device, only
+  the counts leave it.
+
+Results are identical to the reference's (tests/golden/metrics.npz, minted from the imported reference).
 """
 from __future__ import annotations
 
@@ -20,73 +25,108 @@ from . import _lib
 from .heatmap import get_heatmap_expected_value
 
 
+# ----------------------------------------------------------------------------------------------- arg-max
 def get_heatmap_maximum(heatmaps) -> Tuple[np.ndarray, np.ndarray]:
     """heatmap.py:13-52: (K,H,W) or (B,K,H,W) -> locs (..,K,2) f32 (x, y; -1 where the maximum is <= 0), vals (..,K).
     numpy or device tensor in, numpy out; the arg-max runs on the GPU (first maximum in row-major order, like
     np.argmax)."""
+    locs, vals, squeeze = _argmax_device(heatmaps)
+    locs, vals = locs.cpu().numpy(), vals.cpu().numpy()
+    return (locs[0], vals[0]) if squeeze else (locs, vals)
+
+
+def _argmax_device(heatmaps):
     _lib.require_device()
     t = torch.from_numpy(np.ascontiguousarray(heatmaps)) if isinstance(heatmaps, np.ndarray) else heatmaps
     assert t.ndim == 3 or t.ndim == 4, f"Invalid shape {tuple(t.shape)}"
     squeeze = t.ndim == 3
     if squeeze:
         t = t[None]
-    from .codec import ArgMaxProbMap
     B, K, H, W = t.shape
-    out = ArgMaxProbMap((W, H), (W, H), blur_kernel_size=1).decode_device(t.cuda() if not t.is_cuda else t)
-    locs, vals = out["locs"].cpu().numpy(), out["scores"].cpu().numpy()
-    return (locs[0], vals[0]) if squeeze else (locs, vals)
+    t = t.to(device="cuda", dtype=torch.float32).contiguous()
+    locs = torch.empty((B, K, 2), dtype=torch.float32, device="cuda")
+    vals = torch.empty((B, K), dtype=torch.float32, device="cuda")
+    _lib.check(_lib.lib().pp_heatmap_argmax(_lib.ptr(t), B * K, H, W, _lib.ptr(locs), _lib.ptr(vals),
+                                            _lib.stream_ptr()), "pp_heatmap_argmax")
+    return locs, vals, squeeze
 
 
-def _calc_distances(preds: np.ndarray, gts: np.ndarray, mask: np.ndarray, norm_factor: np.ndarray) -> np.ndarray:
-    """heatmap.py:55-89 (note: like the reference, ``norm_factor`` is modified in place where it is <= 0)."""
-    N, K, _ = preds.shape
-    _mask = mask.copy()
-    _mask[np.where((norm_factor == 0).sum(1))[0], :] = False
-    distances = np.full((N, K), -1, dtype=np.float32)
-    norm_factor[np.where(norm_factor <= 0)] = 1e6
-    distances[_mask] = np.linalg.norm(((preds - gts) / norm_factor[:, None, :])[_mask], axis=-1)
-    return distances.T
+# ----------------------------------------------------------------------------------------------- PCK
+def _as_device(x, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+    return t.to(device="cuda", dtype=dtype).contiguous()
 
 
-def _distance_acc(distances: np.ndarray, thr: float = 0.5) -> float:
-    """heatmap.py:92-111."""
-    distance_valid = distances != -1
-    num_distance_valid = distance_valid.sum()
-    if num_distance_valid > 0:
-        return (distances[distance_valid] < thr).sum() / num_distance_valid
-    return -1
+def pck_counts(pred, gt, mask, thr, norm_factor, return_distances: bool = False):
+    """Per-keypoint (hits, valid) over a batch: ``pred`` / ``gt`` (N,K,2), ``mask`` (N,K) bool, ``norm_factor`` (N,2).
+
+    A pair counts as valid when its mask is set and its instance's normalisation factor holds no exact zero; it is a
+    hit when the float32 normalised distance is below ``thr`` (heatmap.py:55-111 semantics, incl. "factor <= 0 -> 1e6").
+    numpy arrays or device tensors; coordinates keep their dtype (float32 locations are subtracted in float32 as numpy
+    does; anything else is handled in float64).  Returns two int64 arrays of length K (and the (K,N) float32 distance
+    matrix, -1 = not valid, when asked)."""
+    _lib.require_device()
+    N, K = int(pred.shape[0]), int(pred.shape[1])
+    is_f32 = (pred.dtype in (np.float32, torch.float32)) and (gt.dtype in (np.float32, torch.float32))
+    cdt = torch.float32 if is_f32 else torch.float64
+    p, g = _as_device(pred, cdt), _as_device(gt, cdt)
+    m = _as_device(mask, torch.bool).view(torch.uint8)
+    nf = np.asarray(norm_factor.cpu() if isinstance(norm_factor, torch.Tensor) else norm_factor)
+    skip = (nf == 0).any(axis=1)
+    nf64 = np.where(nf <= 0, 1e6, nf).astype(np.float64)
+    # `array_f32 < python_float` compares in float32 under numpy 2 (NEP 50: the Python scalar is weak); a numpy
+    # float64 scalar or array threshold would promote the comparison to float64
+    thr_eff = float(np.float32(thr)) if isinstance(thr, (float, int)) and not isinstance(thr, np.generic) else float(thr)
+    counts = torch.empty((2, K), dtype=torch.int32, device="cuda")
+    dist = torch.empty((K, N), dtype=torch.float32, device="cuda") if return_distances else None
+    _lib.check(_lib.lib().pp_pck_counts(_lib.ptr(p), _lib.ptr(g), 0 if is_f32 else 1, _lib.ptr(m),
+                                        _lib.ptr(_as_device(nf64, torch.float64)),
+                                        _lib.ptr(_as_device(skip, torch.bool).view(torch.uint8)), thr_eff, N, K,
+                                        _lib.ptr(counts), _lib.ptr(dist), _lib.stream_ptr()), "pp_pck_counts")
+    c = counts.cpu().numpy().astype(np.int64)
+    return (c[0], c[1], dist.cpu().numpy()) if return_distances else (c[0], c[1])
 
 
-def keypoint_pck_accuracy(pred: np.ndarray, gt: np.ndarray, mask: np.ndarray, thr, norm_factor: np.ndarray) -> tuple:
-    """loss.py:825-866: per-keypoint PCK, their mean over the valid keypoints, and the number of valid keypoints."""
-    distances = _calc_distances(pred, gt, mask, norm_factor)
-    acc = np.array([_distance_acc(d, thr) for d in distances])
-    valid_acc = acc[acc >= 0]
-    cnt = len(valid_acc)
-    avg_acc = valid_acc.mean() if cnt > 0 else 0.0
-    return acc, avg_acc, cnt
+def _accuracy_from_counts(hits: np.ndarray, valid: np.ndarray) -> tuple:
+    acc = np.full(hits.shape, -1.0)
+    seen = valid > 0
+    acc[seen] = hits[seen] / valid[seen]
+    cnt = int(seen.sum())
+    return acc, (acc[seen].mean() if cnt else 0.0), cnt
+
+
+def keypoint_pck_accuracy(pred, gt, mask, thr, norm_factor) -> tuple:
+    """loss.py:825-866: (per-keypoint PCK with -1 for keypoints nobody has, their mean over the others, how many others).
+    Like the reference (heatmap.py:82) a numpy ``norm_factor`` comes back with its non-positive entries set to 1e6."""
+    hits, valid = pck_counts(pred, gt, mask, thr, norm_factor)
+    if isinstance(norm_factor, np.ndarray):
+        norm_factor[norm_factor <= 0] = 1e6
+    return _accuracy_from_counts(hits, valid)
+
+
+def _default_normalize(N, H, W):
+    return np.tile(np.array([[H, W]]), (N, 1))
 
 
 def pose_pck_accuracy(output, target, mask: np.ndarray, thr: float = 0.05, normalize: np.ndarray | None = None,
                       method: str = "argmax") -> tuple:
-    """loss.py:767-822: PCK between the decoded locations of two heatmap batches (N,K,H,W) (numpy or device tensors).
-    ``method`` 'argmax' decodes with get_heatmap_maximum, 'expected' with get_heatmap_expected_value -- which the
-    reference calls WITHOUT sigmas (loss.py:820-821: a TypeError there); ``sigmas`` must therefore be supplied through
-    ``pose_pck_accuracy_expected`` for that method."""
+    """loss.py:767-822: PCK between the peak locations of two heatmap batches (N,K,H,W) (numpy or device tensors).
+    ``method`` 'argmax' locates peaks with get_heatmap_maximum; 'expected' is the branch in which the reference calls
+    get_heatmap_expected_value WITHOUT sigmas (loss.py:820-821: a TypeError there) -- ``pose_pck_accuracy_expected``
+    is that branch made callable."""
     method = method.lower()
     if method not in ["argmax", "expected"]:
         raise ValueError(f"Invalid method: {method}")
     N, K, H, W = output.shape
     if K == 0:
         return None, 0, 0
-    if normalize is None:
-        normalize = np.tile(np.array([[H, W]]), (N, 1))
     if method == "expected":
         raise TypeError("get_heatmap_expected_value() missing 1 required positional argument: 'sigmas' "
                         "(reference loss.py:820 calls it without sigmas; use pose_pck_accuracy_expected)")
-    pred, _ = get_heatmap_maximum(output)
-    gt, _ = get_heatmap_maximum(target)
-    return keypoint_pck_accuracy(pred, gt, mask, thr, normalize)
+    p, _, _ = _argmax_device(output)
+    g, _, _ = _argmax_device(target)
+    hits, valid = pck_counts(p, g, mask, thr, _default_normalize(N, H, W) if normalize is None else normalize)
+    return _accuracy_from_counts(hits, valid)
 
 
 def pose_pck_accuracy_expected(output, target, mask: np.ndarray, sigmas, thr: float = 0.05,
@@ -96,49 +136,65 @@ def pose_pck_accuracy_expected(output, target, mask: np.ndarray, sigmas, thr: fl
     N, K, H, W = output.shape
     if K == 0:
         return None, 0, 0
-    if normalize is None:
-        normalize = np.tile(np.array([[H, W]]), (N, 1))
-    pred, _ = get_heatmap_expected_value(output, sigmas)
-    gt, _ = get_heatmap_expected_value(target, sigmas)
-    return keypoint_pck_accuracy(np.asarray(pred), np.asarray(gt), mask, thr, normalize)
+    p, _ = get_heatmap_expected_value(output, sigmas)
+    g, _ = get_heatmap_expected_value(target, sigmas)
+    hits, valid = pck_counts(np.asarray(p), np.asarray(g), mask, thr,
+                             _default_normalize(N, H, W) if normalize is None else normalize)
+    return _accuracy_from_counts(hits, valid)
+
+
+# ----------------------------------------------------------------------------------------------- OKS
+def _rowsum_like_numpy(values: np.ndarray, keep: np.ndarray) -> np.ndarray:
+    """sum(values[n, keep[n]]) for every row n, each row summed exactly as ``np.sum`` sums the compacted 1-D array
+    (numpy's pairwise scheme assigns elements to partial sums by POSITION, so zero-filling the dropped entries would
+    change the association): rows are grouped by how many entries they keep, each group compacted into a dense
+    (rows, count) block and reduced along its contiguous axis."""
+    out = np.zeros(values.shape[0], dtype=np.float64)
+    count = keep.sum(axis=1)
+    order = np.argsort(~keep, axis=1, kind="stable")        # kept columns first, original order preserved
+    packed = np.take_along_axis(values, order, axis=1)
+    for c in np.unique(count):
+        if c == 0:
+            continue
+        rows = np.nonzero(count == c)[0]
+        out[rows] = np.ascontiguousarray(packed[rows, :c]).sum(axis=1)
+    return out
+
+
+def oks_batch(gt_keypoints, dt_keypoints, bboxes, areas, sigmas, use_area: bool = True, per_kpt: bool = False):
+    """COCO object keypoint similarity of N (annotation, detection) pairs (loss.py:715-764 for every pair at once).
+
+    gt_keypoints / dt_keypoints (N,K,3) = (x, y, visibility); bboxes (N,4) = (x, y, w, h); areas (N,) (used when
+    ``use_area``, else 0.53 * w * h).  Pairs whose annotation has no visible keypoint are scored by the detection's
+    distance to the box grown by its own size on every side, over all K keypoints; the others by the keypoint
+    distances over the visible keypoints.  Returns (N,) similarities, or (N,K) per-keypoint terms (0 at invisible
+    keypoints of annotated instances) with ``per_kpt``."""
+    G = np.asarray(gt_keypoints, dtype=np.float64)
+    D = np.asarray(dt_keypoints, dtype=np.float64)
+    box = np.asarray(bboxes, dtype=np.float64).reshape(-1, 4)
+    N, K = G.shape[0], G.shape[1]
+    variance = (np.asarray(sigmas) * 2) ** 2
+    seen = G[..., 2] > 0
+    annotated = seen.any(axis=1)
+    # distance to the annotation where there is one ...
+    delta = D[..., :2] - G[..., :2]
+    # ... and to the grown box where there is none
+    lo, hi = box[:, None, :2] - box[:, None, 2:], box[:, None, :2] + box[:, None, 2:] * 2
+    outside = np.maximum(0.0, lo - D[..., :2]) + np.maximum(0.0, D[..., :2] - hi)
+    delta = np.where(annotated[:, None, None], delta, outside)
+    size = (np.asarray(areas, dtype=np.float64) if use_area else box[:, 3] * box[:, 2] * 0.53) + np.spacing(1)
+    similarity = np.exp(-((delta[..., 0] ** 2 + delta[..., 1] ** 2) / variance / size[:, None] / 2))
+    if per_kpt:
+        similarity[annotated[:, None] & ~seen] = 0
+        return similarity
+    counted = np.where(annotated[:, None], seen, True)
+    return _rowsum_like_numpy(similarity, counted) / counted.sum(axis=1)
 
 
 def compute_oks(gt, dt, sigmas: np.ndarray, use_area=True, per_kpt=False):
-    """loss.py:715-764: COCO object keypoint similarity of one detection against one annotation."""
-    vars = (sigmas * 2) ** 2
+    """loss.py:715-764, the reference's one-pair interface: ``gt`` = {"keypoints": 3K numbers, "bbox": [x, y, w, h],
+    "area": a}, ``dt`` = {"keypoints": 3K numbers} -> similarity (or the K per-keypoint terms)."""
     k = len(sigmas)
-
-    def visibility_condition(x):
-        return x > 0
-
-    g = np.array(gt["keypoints"]).reshape(k, 3)
-    xg, yg, vg = g[:, 0], g[:, 1], g[:, 2]
-    k1 = np.count_nonzero(visibility_condition(vg))
-    bb = gt["bbox"]
-    x0 = bb[0] - bb[2]
-    x1 = bb[0] + bb[2] * 2
-    y0 = bb[1] - bb[3]
-    y1 = bb[1] + bb[3] * 2
-    d = np.array(dt["keypoints"]).reshape((k, 3))
-    xd, yd = d[:, 0], d[:, 1]
-    if k1 > 0:
-        dx = xd - xg
-        dy = yd - yg
-    else:
-        z = np.zeros((k))
-        dx = np.max((z, x0 - xd), axis=0) + np.max((z, xd - x1), axis=0)
-        dy = np.max((z, y0 - yd), axis=0) + np.max((z, yd - y1), axis=0)
-    if use_area:
-        e = (dx**2 + dy**2) / vars / (gt["area"] + np.spacing(1)) / 2
-    else:
-        tmparea = gt["bbox"][3] * gt["bbox"][2] * 0.53
-        e = (dx**2 + dy**2) / vars / (tmparea + np.spacing(1)) / 2
-    if per_kpt:
-        oks = np.exp(-e)
-        if k1 > 0:
-            oks[~visibility_condition(vg)] = 0
-    else:
-        if k1 > 0:
-            e = e[visibility_condition(vg)]
-        oks = np.sum(np.exp(-e)) / e.shape[0]
-    return oks
+    out = oks_batch(np.asarray(gt["keypoints"]).reshape(1, k, 3), np.asarray(dt["keypoints"]).reshape(1, k, 3),
+                    [gt["bbox"]], [gt["area"]] if use_area else [0.0], sigmas, use_area=use_area, per_kpt=per_kpt)
+    return out[0]
