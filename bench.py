@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: person-crops/sec (+ decode ms) of the ProbPose forward +
 decode path, ViT-B 256x192 K=17 bf16, batch 64 per MI355X (BASELINE.json
-configs[1]).  One process per GPU; for N > 1 launch with torch.distributed.run
-(rank r takes crops [r*64, (r+1)*64) of the global batch, weak scaling) and the
-decoded keypoints are all-gathered over RCCL every step.
+configs[1]).  One process per GPU (rank r takes crops [r*64, (r+1)*64) of the
+global batch, weak scaling); the decoded keypoints are all-gathered over RCCL
+every step.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 ...      # starts its own 8 ranks (see launch_ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus 8 ...      # or under an external launcher
 
 Prints ONE JSON line on rank 0.  A step = patchify -> ViT -> ProbMapHead ->
 fused decode (-> all-gather), inputs resident in HBM, synthetic crops and
@@ -126,13 +129,13 @@ def decode_at_scale(codec, K, H4, W4, device, iters: int = 20):
     kpts = torch.empty((B, K, 2), dtype=torch.float64, device=device)
     scores = torch.empty((B, K), dtype=torch.float32, device=device)
     locs = torch.empty((B, K, 2), dtype=torch.float32, device=device)
-    ws = torch.empty((max(int(L.pp_decode_workspace_bytes(B, K, H4, W4)), 4),), dtype=torch.uint8, device=device)
+    ws = torch.zeros((max(int(L.pp_decode_workspace_bytes(B, K, H4, W4)), 16),), dtype=torch.uint8, device=device)
     stream = _lib.stream_ptr()
 
     def call():
         rc = L.pp_decode_f32(_lib.ptr(hm), None, None, None, None, B, K, H4, W4, _lib.ptr(taps), _lib.ptr(radius),
                              float(W4 - 1), float(H4 - 1), float(4 * W4), float(4 * H4), _lib.ptr(kpts), _lib.ptr(scores),
-                             _lib.ptr(locs), None, None, None, None, _lib.ptr(ws), stream)
+                             _lib.ptr(locs), None, None, None, None, _lib.ptr(ws), 0, stream)
         _lib.check(rc, "pp_decode_f32")
 
     for _ in range(3):
@@ -175,6 +178,28 @@ def build(cfg, dtype, device):
     return model, codec, sd
 
 
+def _progress(msg: str) -> None:
+    """One line on stderr per phase: stdout carries only the JSON line; a silent run reads as hung to the GPU box."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """(threads to use, description): os.cpu_count() bounded by the affinity mask and by the cgroup CPU quota of this
+    process -- more OpenMP threads than the container may run makes every CPU matmul spin against itself."""
+    total = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = max(1, int(float(q) / float(period) + 0.5))
+    except (OSError, ValueError):
+        pass
+    n = max(1, min(v for v in (total, affinity, quota) if v))
+    return n, f"os.cpu_count() {total}, affinity mask {affinity}, cgroup quota {quota if quota else 'none'} -> {n} threads"
+
+
 def _cpu_pass(orc, sd, cfg, x, sig):
     """One forward + decode pass of the CPU path; returns (forward s, decode s)."""
     H, W = cfg["img"]
@@ -186,24 +211,32 @@ def _cpu_pass(orc, sd, cfg, x, sig):
     return t1 - t0, time.perf_counter() - t1
 
 
-def cpu_baseline(cfg, sd, seconds_budget: float = 18.0):
+def cpu_baseline(cfg, sd, seconds_budget: float = 60.0):
     """The reference's CPU path (restated in oracle/, pinned on the reference's goldens): plain PyTorch fp32 eval
-    forward + per-crop scipy decode on this host's cores.  BASELINE.md section 3: median of 5 passes after 2
-    warm-ups over a bounded sample of the bench workload, forward and decode ms/crop from the SAME passes, plus the
-    S1 line (ViT-S, one crop: forward + decode latency)."""
+    forward + per-crop scipy decode on this host's cores, BASELINE.md section 3's B64 line: the FULL batch of the bench
+    workload (64 crops for ViT-B; fewer only if a pass would not fit the time budget -- stated in `sample`),
+    torch.set_num_threads(os.cpu_count()), 1 warm-up + 3 timed passes, median; forward and decode ms/crop from the same
+    passes; plus the S1 line (ViT-S, one crop: forward + decode latency, median of 5 after 2 warm-ups)."""
     from oracle import probpose_oracle as orc
     from probpose_pytorch_amd.synthetic import synthetic_crops, synthetic_model_state
     H, W = cfg["img"]
-    cores = torch.get_num_threads()
+    cores, cores_how = host_cores()
+    torch.set_num_threads(cores)
+    _progress(f"cpu_baseline: {cores_how}")
     sig = sigmas_for(cfg["K"])
     f, d = _cpu_pass(orc, sd, cfg, synthetic_crops(2, H, W, seed=99), sig)     # calibration (also a warm-up)
     per_crop = (f + d) / 2
-    n = int(max(2, min(cfg["batch"], seconds_budget / 7 / max(per_crop, 1e-3))))
+    n = int(max(2, min(cfg["batch"], seconds_budget / 4 / max(per_crop, 1e-3))))
+    _progress(f"cpu_baseline: calibration {per_crop * 1e3:.0f} ms/crop -> {n} crops per pass, 1 warm-up + 3 timed passes")
     x = synthetic_crops(n, H, W, seed=1234)
-    passes = [_cpu_pass(orc, sd, cfg, x, sig) for _ in range(7)][2:]             # 2 warm-ups, 5 timed
-    tot = sorted(f_ + d_ for f_, d_ in passes)[2]
-    fwd = sorted(f_ for f_, _ in passes)[2]
-    dec = sorted(d_ for _, d_ in passes)[2]
+    passes = []
+    for i in range(4):                                                           # 1 warm-up, 3 timed
+        passes.append(_cpu_pass(orc, sd, cfg, x, sig))
+        _progress(f"cpu_baseline: pass {i} forward {passes[-1][0]:.1f} s decode {passes[-1][1]:.1f} s")
+    passes = passes[1:]
+    tot = sorted(f_ + d_ for f_, d_ in passes)[1]
+    fwd = sorted(f_ for f_, _ in passes)[1]
+    dec = sorted(d_ for _, d_ in passes)[1]
     # S1 (BASELINE.json configs[0]): single 256x192 crop, ViT-S (C 384, depth 12, 12 heads), K = 17
     s1 = dict(CONFIGS["vit_s"])
     sd1 = synthetic_model_state(s1["img"], 16, s1["C"], s1["depth"], s1["K"], len(s1["pools"]), (256, 256), seed=0)
@@ -211,8 +244,10 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 18.0):
     sig1 = sigmas_for(s1["K"])
     p1 = [_cpu_pass(orc, sd1, s1, x1, sig1) for _ in range(7)][2:]
     return {"value": round(n / tot, 3), "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"{n} crops of the bench workload, torch fp32 CPU eval forward + per-crop scipy decode "
-                      f"(oracle/probpose_oracle.py); median of 5 passes after 2 warm-ups",
+            "threads": f"torch.set_num_threads({cores}): {cores_how}",
+            "sample": f"{n} crops = {'the full batch' if n == cfg['batch'] else 'a bounded part'} of the bench workload "
+                      f"(batch {cfg['batch']}), torch fp32 CPU eval forward + per-crop scipy decode "
+                      f"(oracle/probpose_oracle.py); median of 3 passes after 1 warm-up",
             "forward_ms_per_crop": round(fwd / n * 1e3, 2), "decode_ms_per_crop": round(dec / n * 1e3, 3),
             "s1_vit_s_single_crop": {"forward_ms": round(sorted(f_ for f_, _ in p1)[2] * 1e3, 2),
                                      "decode_ms": round(sorted(d_ for _, d_ in p1)[2] * 1e3, 2),
@@ -264,6 +299,31 @@ def parity_block(cfg, sd, model, codec, x, dtype, n_crops: int = 8, fp32_steps: 
     return res
 
 
+def launcher_command(argv, n_ranks: int, port: int):
+    """argv of the N-rank launch of this script: one process per GPU under torch.distributed.run, rendezvous on
+    127.0.0.1 (the container hostname may not resolve).  ``argv`` = this script's own arguments, passed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(argv, n_ranks: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: THIS process has made no GPU call and makes none (the build
+    runs in a child too -- loading the HIP library is the child's business); it starts the N ranks as a child process
+    tree, relays their output (rank 0 prints the one JSON line) and returns their exit status.  Never an exec: a process
+    that touched the GPU must not be replaced, and the children each initialise their own device."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    rc = subprocess.call([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, env=env)
+    if rc != 0:
+        return rc
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return subprocess.call(launcher_command(argv, n_ranks, port), cwd=ROOT, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +345,9 @@ def main():
                     help="JSON file of per-shape GEMM tile winners: loaded if present, written after the warm-up "
                          "(lets a profiled run start tuned, so its trace holds no tuning launches)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -326,6 +389,8 @@ def main():
         _engine.SERIALIZE_HEAD = True
     if args.tune_cache and os.path.exists(args.tune_cache):
         ops.load_tune_cache(args.tune_cache)
+    if rank == 0:
+        _progress(f"building {args.config} ({args.dtype}), batch {B}/GPU, world {world}")
     model, codec, sd = build(cfg, dtype, device)
     x = synthetic_crops(B, H, W, seed=1234 + rank).to(device)       # resident in HBM before timing
 
@@ -373,6 +438,8 @@ def main():
                 torch.cuda.synchronize()
 
         sync_all()
+        if rank == 0:
+            _progress(f"warm-up done (tiles tuned, graph {'captured' if graph is not None else 'off'}); timing {args.steps} steps")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             result = step(run_local)
@@ -442,8 +509,10 @@ def main():
             line["measured_device_peaks"] = mp
             if args.dtype == "bf16":
                 line["roofline"]["frac_of_measured_mfma"] = round(achieved / mp["mfma_bf16_random_tflops"], 4)
+        _progress(f"timed region done: {ms_per_step:.3f} ms/step; parity block / CPU baseline follow")
         if world == 1 and not args.no_parity:
             line["parity"] = parity_block(cfg, sd, model, codec, x, dtype)
+            _progress("parity block done")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(line))

@@ -54,6 +54,9 @@ extern "C" {
                                            (head.py:525-532) to the ReLU'd tile: C is the f32 NCHW heat buffer [B, hm_K, hm_HW],
                                            final_w [hm_K, 256] bf16, final_b [hm_K] f32, hm_K <= 32; the 256-channel map is
                                            never stored.  out_rowmap gives each GEMM row its pixel index b * hm_HW + hw. */
+#define PP_EPI_HEADMAJOR 4096            /* bf16 qkv projection (timm attn.qkv): C is written [3][heads][M][head_dim] instead of
+                                           [M][3 * heads * head_dim]; heads = hm_K, head_dim = hm_HW (fields reused), N = 3 * hm_K *
+                                           hm_HW.  Read by pp_attention_headmajor. */
 #define PP_EPI_HEATMAP 64               /* head.py:526-532: f32 NCHW store of clamp(v / temperature, 0, 1):
                                            C[((r / hm_HW) * hm_K + n) * hm_HW + r % hm_HW], r = output row */
 
@@ -63,7 +66,8 @@ const char *pp_last_error(void);
 int pp_device_ok(void);
 
 /* ------------------------------------------------------------------------
- * Fused decode.  Replaces, in one launch per batch:
+ * Fused decode.  Replaces, in one launch per batch (64x48 and 96x72 maps with a workspace, and every map that fits LDS;
+ * maps beyond LDS -- e.g. 256x256 -- take three launches through a global-memory image):
  *   Codec.decode            probpose/codec.py:249-263
  *   ProbMap.decode          probpose/codec.py:214-239
  *   get_heatmap_expected_value + _get_subpixel_maximums
@@ -81,17 +85,23 @@ int pp_device_ok(void);
  * (prob,vis,oks passthrough), err f64 [B,K] (= err / sqrt(H^2+W^2)),
  * conv f32 [B,K,H,W] (return_heatmap=True), packed f64 [B,K,7] = (kpt x, kpt y,
  * score, prob, vis, oks, err) per keypoint: the record the multi-GPU all-gather ships.
- * workspace: pp_decode_workspace_bytes() bytes, 4-byte aligned: a (B*K + 1)-int hand-over list for 64x48 / 96x72 maps
- * (the fast path; NULL selects the workgroup-per-map kernels instead), 0 for other maps that fit in LDS, a float64 +
- * float32 image of the batch for maps that do not.
+ * workspace: pp_decode_workspace_bytes() bytes, 4-byte aligned: a (B*K + 4)-int work list for 64x48 / 96x72 maps (the
+ * fast path; NULL selects the workgroup-per-map kernels instead) which the caller ZEROES ONCE when it allocates it (every
+ * launch returns it to zero itself) and must not share between launches that may run concurrently; 0 for other maps that
+ * fit in LDS; a float64 + float32 image of the batch for maps that do not.
+ * flags: 0 = the default form per map size; PP_DECODE_NO_WAVE / PP_DECODE_SCREEN / PP_DECODE_ALL_PIXEL select the
+ * other implementations (A/B measurements and the equivalence tests: all forms return identical numbers).
  * ---------------------------------------------------------------------- */
+#define PP_DECODE_NO_WAVE 1             /* not the wave-per-map kernel (64x48 / 96x72 maps)                  */
+#define PP_DECODE_SCREEN 2              /* the workgroup-per-map screened kernel on every map that fits LDS  */
+#define PP_DECODE_ALL_PIXEL 4           /* float64 convolution of every pixel (the round-1 kernel)          */
 size_t pp_decode_workspace_bytes(int B, int K, int H, int W);
 int pp_decode_f32(const float *heatmaps, const float *prob, const float *vis,
                   const float *oks, const float *err, int B, int K, int H, int W,
                   const double *taps, const int *radius, double den_x, double den_y,
                   double in_w, double in_h, double *out_kpts, float *out_scores,
                   float *out_locs, float *out_aux, double *out_err, float *out_conv,
-                  double *out_packed, void *workspace, void *stream);
+                  double *out_packed, void *workspace, int flags, void *stream);
 
 /* ------------------------------------------------------------------------
  * Dense contraction on MFMA:  C[M,N] = epilogue(A[M,Kd] * W[N,Kd]^T).
@@ -172,6 +182,10 @@ int pp_layernorm_fp8(const float *x, const float *gamma, const float *beta, floa
  * reshape(B,N,3,heads,hd)); out [B*N, heads*hd]. */
 int pp_attention(const void *qkv, void *out, int B, int N, int heads, int hd,
                  int dtype, void *stream);
+/* Same attention on a HEAD-MAJOR bf16 qkv, [3][heads][B*N][hd] as the qkv GEMM writes it with PP_EPI_HEADMAJOR (one
+ * head's rows contiguous: whole cache lines for head_dim 80 / 32); out [B*N, heads*hd] row-major as above.
+ * The streaming MFMA kernel, head_dim 32 / 64 / 80, any N. */
+int pp_attention_headmajor(const void *qkv, void *out, int B, int N, int heads, int hd, void *stream);
 /* Same on bf16 qkv, output quantised to OCP e4m3: out[., c] = e4m3(o * inv_scale) (fp8 mode: the A operand of
  * the fp8 proj GEMM).  MFMA kernels only (head_dim 32 / 64 / 80). */
 int pp_attention_fp8out(const void *qkv, unsigned char *out, int B, int N, int heads, int hd,

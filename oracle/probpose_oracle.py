@@ -271,15 +271,22 @@ def sparsemax_lastdim(x: torch.Tensor) -> torch.Tensor:
     return torch.max(torch.zeros_like(z), z - taus)
 
 
-def head_forward_heatmap(sd, x, *, n_deconv: int, final_kernel: int = 1,
-                         temperature: float = 0.5, normalize=None, prefix: str = ""):
-    """head.py:513-534 with deconv stack head.py:433-474 (k4 s2 p1, no bias)."""
+def head_forward_heatmap(sd, x, *, n_deconv: int, final_kernel=1,
+                         temperature: float = 0.5, normalize=None, prefix: str = "", conv_kernels: Sequence[int] = ()):
+    """head.py:513-534 with the deconv stack head.py:433-474 (k4 s2 p1, no bias), the optional conv stack
+    head.py:407-431 (Conv2d k, stride 1, padding (k-1)//2, bias -> BN -> ReLU) and the final layer head.py:227-235
+    (Conv2d k, padding k//2; ``final_kernel=None``: nn.Identity)."""
     for i in range(n_deconv):
         x = F.conv_transpose2d(x, sd[f"{prefix}deconv_layers.{3 * i}.weight"], None,
                                stride=2, padding=1, output_padding=0)
         x = F.relu(_bn(sd, f"{prefix}deconv_layers.{3 * i + 1}.", x))
-    x = F.conv2d(x, sd[prefix + "final_layer.weight"], sd[prefix + "final_layer.bias"],
-                 padding=final_kernel // 2)                       # :227-233,525
+    for i, k in enumerate(conv_kernels):                          # :407-431,524
+        x = F.conv2d(x, sd[f"{prefix}conv_layers.{3 * i}.weight"], sd[f"{prefix}conv_layers.{3 * i}.bias"],
+                     padding=(k - 1) // 2)
+        x = F.relu(_bn(sd, f"{prefix}conv_layers.{3 * i + 1}.", x))
+    if final_kernel is not None:
+        x = F.conv2d(x, sd[prefix + "final_layer.weight"], sd[prefix + "final_layer.bias"],
+                     padding=final_kernel // 2)                   # :227-233,525
     B, C, H, W = x.shape
     x = x.reshape(B, C, H * W) / temperature                      # :527-528
     if normalize is not None:                                     # :528-530 (parity unpinned, see sparsemax_lastdim)
@@ -300,12 +307,12 @@ def head_forward_aux(sd, x, name: str, pools: Sequence, last: str, prefix: str =
     return torch.sigmoid(x) if last == "sigmoid" else F.relu(x)
 
 
-def head_forward(sd, feats, *, pools, n_deconv: int = 2, final_kernel: int = 1,
-                 prefix: str = "", normalize=None):
+def head_forward(sd, feats, *, pools, n_deconv: int = 2, final_kernel=1,
+                 prefix: str = "", normalize=None, conv_kernels: Sequence[int] = ()):
     """ProbMapHead.forward (eval).  head.py:487-511."""
     return (
         head_forward_heatmap(sd, feats, n_deconv=n_deconv, final_kernel=final_kernel, prefix=prefix,
-                             normalize=normalize),
+                             normalize=normalize, conv_kernels=conv_kernels),
         head_forward_aux(sd, feats, "probability", pools, "sigmoid", prefix),
         head_forward_aux(sd, feats, "visibility", pools, "sigmoid", prefix),
         head_forward_aux(sd, feats, "oks", pools, "sigmoid", prefix),

@@ -12,6 +12,8 @@ PP_F32, PP_BF16, PP_FP8 = 0, 1, 2
 PP_MAX_RADIUS = 9
 PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS, EPI_HEATMAP = 1, 2, 4, 8, 16, 32, 64
+DECODE_NO_WAVE, DECODE_SCREEN, DECODE_ALL_PIXEL = 1, 2, 4
+EPI_HEADMAJOR = 4096
 EPI_OUT_FP8, EPI_NOCLAMP, EPI_FUSE_FINAL = 512, 1024, 2048      # 128 / 256: retired (LayerNorm fusion, round 1)
 
 _lock = threading.Lock()
@@ -50,11 +52,12 @@ _SIGNATURES = {
     "pp_last_error": (C.c_char_p, []),
     "pp_device_ok": (C.c_int, []),
     "pp_decode_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
-    "pp_decode_f32": (C.c_int, [_vp] * 5 + [_i] * 4 + [_vp, _vp] + [_d] * 4 + [_vp] * 9),
+    "pp_decode_f32": (C.c_int, [_vp] * 5 + [_i] * 4 + [_vp, _vp] + [_d] * 4 + [_vp] * 8 + [_i, _vp]),
     "pp_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "pp_layernorm": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "pp_layernorm_fp8": (C.c_int, [_vp, _vp, _vp, _f, _i, _i, _vp, _f, _vp]),
     "pp_attention": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "pp_attention_headmajor": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "pp_attention_fp8out": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "pp_patchify": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "pp_maxpool_relu": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

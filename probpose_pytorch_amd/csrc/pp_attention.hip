@@ -352,7 +352,7 @@ template <int HD, int NW, int ST_QT, int ST_KB>
 __global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16_t *__restrict__ qkv,
                                                                   bf16_t *__restrict__ out, int N, int heads,
                                                                   int qblocks, int nprob, float scale_log2e,
-                                                                      float fp8_inv_scale) {
+                                                                      float fp8_inv_scale, int headmajor) {
   using G = AttGeom<HD>;
   constexpr int KROW = G::KROW;
   constexpr int BLK_BYTES = ST_KB * KROW;
@@ -366,8 +366,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16
   const int qb = wx % qblocks, bh = (wx / qblocks) * 8 + xcd;
   if (bh >= nprob) return;                   // the grid is rounded up to whole groups of 8 problems
   const int b = bh / heads, h = bh - b * heads;
-  const int C = heads * HD, ld = 3 * C;
-  const bf16_t *base = qkv + (size_t)b * N * ld + h * HD;
+  const int C = heads * HD;
+  // row-major qkv [B*N][3][heads][HD] (timm's layout): a head's rows sit 3 C apart.  Head-major qkv
+  // [3][heads][B*N][HD] (PP_EPI_HEADMAJOR of the qkv GEMM): they are contiguous -- a 160-byte head row (HD = 80) then
+  // fills whole cache lines instead of touching 2 - 3 of them at a 7 680-byte stride.
+  const size_t plane = (size_t)heads * (nprob / heads) * N * HD;          // one of q / k / v, head-major
+  const int ld = headmajor ? HD : 3 * C;
+  const size_t kofs = headmajor ? plane : (size_t)C, vofs = 2 * kofs;
+  const bf16_t *base = headmajor ? qkv + ((size_t)h * (nprob / heads) + b) * N * HD : qkv + (size_t)b * N * ld + h * HD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, g = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
@@ -409,8 +415,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16
         const bf16_t *src = base + (size_t)key * ld + G::swz(row, pchunk) * 8;
         const unsigned dst = __builtin_amdgcn_readfirstlane(slot + pc * 1024);
         const void *zsrc = g_att_zero + lane * 16;
-        att_glds16(key < N ? (const void *)(src + C) : zsrc, dst);
-        att_glds16(key < N ? (const void *)(src + 2 * C) : zsrc, dst + BLK_BYTES);
+        att_glds16(key < N ? (const void *)(src + kofs) : zsrc, dst);
+        att_glds16(key < N ? (const void *)(src + vofs) : zsrc, dst + BLK_BYTES);
       }
     }
   };
@@ -557,27 +563,34 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16
 }
 
 template <int HD, int NW, int QT, int KB>
-static int launch_stream_cfg(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s) {
+static int launch_stream_cfg(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s,
+                             int headmajor) {
   const int qblocks = (N + NW * QT * 16 - 1) / (NW * QT * 16);
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)HD);
   const int nprob = B * heads;
   constexpr int LDS = 4 * KB * AttGeom<HD>::KROW;     // two slots of K + V
   hipLaunchKernelGGL((attention_stream_kernel<HD, NW, QT, KB>), dim3((unsigned)((size_t)((nprob + 7) / 8) * 8 * qblocks)),
                      dim3(NW * 64), LDS, s, (const bf16_t *)qkv, (bf16_t *)out, N, heads, qblocks, nprob, scale_log2e,
-                     fp8_inv_scale);
+                     fp8_inv_scale, headmajor);
   return 0;
 }
 
 // 144-query workgroups (3 waves x 3 tiles) when they waste fewer query rows than 128-query ones (4 waves x 2); the
 // key block shrinks to 32 rows there (hd 64 / 80: 3 score tiles per key tile would not fit 168 registers otherwise).
-// PP_ATT_STREAM = 4 / 3 forces one form (lab use).
+// Lab builds only (-DPP_ATT_LAB, tools/): the environment variable PP_ATT_STREAM = 4 / 3 forces one form.  The shipped
+// library reads no environment.
 template <int HD>
-static int launch_stream(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s) {
+static int launch_stream(const void *qkv, void *out, int B, int N, int heads, float fp8_inv_scale, hipStream_t s,
+                         int headmajor = 0) {
+#ifdef PP_ATT_LAB
   static const int forced = []() { const char *e = getenv("PP_ATT_STREAM"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int forced = 0;
+#endif
   const int waste128 = (N + 127) / 128 * 128 - N, waste144 = (N + 143) / 144 * 144 - N;
   const bool use144 = forced ? forced != 4 : waste144 < waste128;
-  if (use144) return launch_stream_cfg<HD, 3, 3, 32>(qkv, out, B, N, heads, fp8_inv_scale, s);
-  return launch_stream_cfg<HD, 4, 2, 64>(qkv, out, B, N, heads, fp8_inv_scale, s);
+  if (use144) return launch_stream_cfg<HD, 3, 3, 32>(qkv, out, B, N, heads, fp8_inv_scale, s, headmajor);
+  return launch_stream_cfg<HD, 4, 2, 64>(qkv, out, B, N, heads, fp8_inv_scale, s, headmajor);
 }
 
 }  // namespace pp
@@ -632,4 +645,20 @@ extern "C" int pp_attention_fp8out(const void *qkv, unsigned char *out, int B, i
                                    float inv_scale, void *stream) {
   if (!(inv_scale > 0.f)) return pp::fail("pp_attention_fp8out: inv_scale must be positive");
   return attention_dispatch(qkv, out, B, N, heads, hd, PP_BF16, inv_scale, stream);
+}
+
+/* Head-major qkv: see include/probpose_hip.h.  The streaming MFMA kernel only (bf16, head_dim 32 / 64 / 80, any N). */
+extern "C" int pp_attention_headmajor(const void *qkv, void *out, int B, int N, int heads, int hd, void *stream) {
+  using namespace pp;
+  PP_REQUIRE(B >= 0 && N > 0 && heads > 0 && hd > 0, "pp_attention_headmajor: bad shape");
+  if (B == 0) return 0;
+  PP_REQUIRE(qkv && out, "pp_attention_headmajor: null pointer");
+  PP_REQUIRE((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0,
+             "pp_attention_headmajor: head_dim 32 / 64 / 80, qkv 16-byte aligned (got head_dim %d)", hd);
+  hipStream_t s = (hipStream_t)stream;
+  if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, 0.f, s, 1);
+  else if (hd == 64) launch_stream<64>(qkv, out, B, N, heads, 0.f, s, 1);
+  else launch_stream<32>(qkv, out, B, N, heads, 0.f, s, 1);
+  PP_CHECK_LAUNCH("attention_stream_kernel (head-major)");
+  return 0;
 }

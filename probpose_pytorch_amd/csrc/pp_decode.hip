@@ -17,7 +17,7 @@
 //     (heatmap.py:114-167); compiled with -ffp-contract=off so no FMA fuses
 //     what numpy evaluates as separate float32 operations.
 //   * rescale in float64: locs / (size-1) * input_size (codec.py:237).
-#include <stdlib.h>
+#include <algorithm>
 
 #include "pp_common.h"
 
@@ -165,7 +165,7 @@ constexpr int DEC_HALO = 12;  // reflected halo columns on each side of a row in
 // The raw map sits in LDS with a reflected halo (rawp, row stride WP), so every row window is read
 // with 16-B aligned, lane-consecutive ds_read_b128: the stride-4 scalar reads this replaces were an
 // 8-way LDS bank conflict and made the row pass LDS-bound.
-template <int R>
+template <int R, int NT>   // NT = threads of the workgroup
 __device__ __forceinline__ void conv_passes(const float *__restrict__ rawp, int WP, float *__restrict__ buf,
                                             double *__restrict__ tmp, int H, int W,
                                             const double (&wk)[PP_MAX_TAPS], float *__restrict__ out_conv_map,
@@ -178,9 +178,9 @@ __device__ __forceinline__ void conv_passes(const float *__restrict__ rawp, int 
 #pragma unroll
   for (int j = 0; j < T; ++j) w[j] = wk[j];  // block-uniform -> scalar registers
 
-  // one division per thread up front, then (row, column-group) advances incrementally by DEC_THREADS items
+  // one division per thread up front, then (row, column-group) advances incrementally by NT items
   const int W4 = (W + 3) >> 2;
-  const int step_y = DEC_THREADS / W4, step_x = DEC_THREADS - step_y * W4;
+  const int step_y = NT / W4, step_x = NT - step_y * W4;
   {
     int y = tid / W4, xg = tid - y * W4;
     for (; y < H;) {
@@ -228,7 +228,7 @@ __device__ __forceinline__ void conv_passes(const float *__restrict__ rawp, int 
 #endif
 
   const int H4 = (H + 3) >> 2;
-  const int cstep_y = DEC_THREADS / W, cstep_x = DEC_THREADS - cstep_y * W;
+  const int cstep_y = NT / W, cstep_x = NT - cstep_y * W;
   const bool one_reflection_y = H >= R + 3;
   {
     int y4 = tid / W, x = tid - y4 * W;
@@ -280,6 +280,7 @@ __device__ __forceinline__ void conv_passes(const float *__restrict__ rawp, int 
   }
 }
 
+template <int NT>
 __device__ __forceinline__ void decode_lds_map(
     const int map, char *smem, Best *red, const float *__restrict__ heatmaps, const float *prob, const float *vis,
     const float *oks, const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
@@ -306,9 +307,9 @@ __device__ __forceinline__ void decode_lds_map(
   if ((W & 3) == 0) {
     const int W4 = W >> 2;
     const float4 *s4 = reinterpret_cast<const float4 *>(src);
-    const int sy = DEC_THREADS / W4, sx = DEC_THREADS - sy * W4;
+    const int sy = NT / W4, sx = NT - sy * W4;
     int y = tid / W4, xq = tid - y * W4;
-    for (int p = tid; p < H * W4; p += DEC_THREADS) {
+    for (int p = tid; p < H * W4; p += NT) {
       *reinterpret_cast<float4 *>(rawp + y * WP + DEC_HALO + 4 * xq) = s4[p];
       y += sy;
       xq += sx;
@@ -318,7 +319,7 @@ __device__ __forceinline__ void decode_lds_map(
       }
     }
   } else {
-    for (int p = tid; p < HW; p += DEC_THREADS) {
+    for (int p = tid; p < HW; p += NT) {
       const int y = p / W, x = p - y * W;
       rawp[y * WP + DEC_HALO + x] = src[p];
     }
@@ -329,7 +330,7 @@ __device__ __forceinline__ void decode_lds_map(
     if (q < npad) {
       const int col = q < DEC_HALO ? q : q + W;       // padded column index
       const int sx = reflect_idx(col - DEC_HALO, W);
-      for (int y = tid >> 5; y < H; y += DEC_THREADS / 32) rawp[y * WP + col] = src[y * W + sx];
+      for (int y = tid >> 5; y < H; y += NT / 32) rawp[y * WP + col] = src[y * W + sx];
     }
   }
   __syncthreads();
@@ -347,14 +348,14 @@ __device__ __forceinline__ void decode_lds_map(
   dbgp = dbg_st;
 #endif
   switch (r) {  // block-uniform
-    case 2: conv_passes<2>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    case 3: conv_passes<3>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    case 4: conv_passes<4>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    case 5: conv_passes<5>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    case 6: conv_passes<6>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    case 7: conv_passes<7>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    case 8: conv_passes<8>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
-    default: conv_passes<9>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 2: conv_passes<2, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 3: conv_passes<3, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 4: conv_passes<4, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 5: conv_passes<5, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 6: conv_passes<6, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 7: conv_passes<7, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    case 8: conv_passes<8, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
+    default: conv_passes<9, NT>(rawp, WP, buf, tmp, H, W, wk, ocm, mine.v, mine.i, have, dbgp); break;
   }
   if (!have) {  // more threads than pixels: never wins
     mine.v = -__builtin_inff();
@@ -387,25 +388,8 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_kernel(
     DecodeOut o, float *__restrict__ out_conv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ Best red[DEC_THREADS / 64];
-  decode_lds_map(blockIdx.x, smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w,
-                 in_h, o, out_conv);
-}
-
-// The same all-pixel float64 decode over a LIST of maps written by an earlier kernel of the stream (the wave-per-map
-// kernel hands over the maps its float32 screen cannot settle cheaply): list[0] = count, list[1 ..] = map indices.
-// The grid is fixed (graph-capturable); workgroups stride over the list and leave at once when it is empty.
-__global__ __launch_bounds__(DEC_THREADS) void decode_lds_list_kernel(
-    const int *__restrict__ list, const float *__restrict__ heatmaps, const float *prob, const float *vis,
-    const float *oks, const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
-    const int *__restrict__ radius, double den_x, double den_y, double in_w, double in_h, DecodeOut o) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ Best red[DEC_THREADS / 64];
-  const int n = list[0];
-  for (int b = blockIdx.x; b < n; b += gridDim.x) {
-    decode_lds_map(list[1 + b], smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w,
-                   in_h, o, nullptr);
-    __syncthreads();                     // the next map reuses the LDS image and the reduction slots
-  }
+  decode_lds_map<DEC_THREADS>(blockIdx.x, smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x,
+                              den_y, in_w, in_h, o, out_conv);
 }
 
 // ---------------------------------------------------------------------------
@@ -749,13 +733,31 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 //      candidates -> exact float64 value of each candidate by T lanes (one row chain each, the map re-read from L2) +
 //      the column chain; then the four neighbours of the winner in one more round of 3T + 2 row chains; finalize()
 //      on lane 0.
-// Non-finite maps and flat maps (clamped plateaus: more than DWV_MAXCAND candidates) are not settled here: the wave
-// appends the map to a list in the workspace and the all-pixel float64 kernel (decode_lds_list_kernel) that follows
-// on the stream decodes exactly those maps.  (A wave-local exact path for them -- row chains shared through an LDS ring
-// -- was built and measured at 150 us per 64-crop batch of random-weight heatmaps against 24 us for this hand-over:
-// one wave's float64 chains are latency-bound and its register file is too small to interleave enough of them.)
-// (Per-map flags instead of the counted list -- no memset, no atomics -- made the hand-over kernel scan every map:
-// 109 against 99 us at B = 1024, 36 against 33 us on the model's maps; the list stayed.)
+// Non-finite maps and flat maps (clamped plateaus: more than DWV_MAXCAND candidates) are not settled by a wave: it
+// pushes the map onto a work list in the workspace and WHOLE WORKGROUPS of the same launch decode those maps with the
+// all-pixel float64 algorithm (decode_lds_map) -- one launch, no count-reset kernel, no follow-up kernel (round 2 ran
+// three launches: 5 + 21 + 14 us at bs 64).  Who pops the list:
+//   * HELPER workgroups (block ids behind the screening ones, a fixed few) that own no maps: they poll the list from
+//     one lane every ~2 us (s_sleep between polls: a counter word serves ~88 atomics per us chip-wide, so the pollers
+//     must stay far below that or they starve the workgroups that do the work -- the first version of this kernel had
+//     every workgroup pop and 136 - 256 helpers poll back to back: 7 ms per launch), so a plateau map found 3 us into
+//     the launch is decoded beside the screening instead of after it;
+//   * the LAST screening workgroup to finish (it knows from the counter every screening workgroup bumps once) drains
+//     whatever is left: by then every push has happened, so results never depend on a helper having run (helpers give
+//     up after a bounded number of polls; speed only, never correctness).
+// The other screening workgroups touch the list with exactly one atomic (their arrival).
+// A flat map is recognised EARLY where possible (many pixels at the map's maximum right after the load: the clamp's
+// plateau) and pushed before the float32 passes; maps that only turn out flat in the screen are pushed then.
+// List protocol (ints in the workspace, all zero between launches: the launch returns them to zero itself, so no memset
+// node is needed; the caller zeroes the workspace once when it allocates it): [0] pushed, [1] taken, [2] screening
+// workgroups done, [3] leavers (helpers + the last screening workgroup), [4 ..] slots holding map + 1.  Push: reserve a
+// slot (atomic add), write it (agent-scope store), drain (vmcnt 0) before the workgroup reports itself done.  Pop: CAS
+// on `taken`, then wait for the slot to turn non-zero (its writer is two instructions behind its reservation) and clear
+// it.  Every access is an agent-scope atomic (sc1: served by memory, not by an XCD-private L2 line), the payload is a
+// 4-byte index, the heatmaps themselves are inputs nobody writes.  The last leaver zeroes the four counters: only
+// helpers and the last screening workgroup ever read them, and all of those have left by then.
+// (A wave-local exact path for flat maps -- row chains shared through an LDS ring -- was built in round 2 and measured
+// at 150 us per 64-crop batch of random-weight heatmaps: one wave's float64 chains are latency-bound.)
 // ---------------------------------------------------------------------------
 constexpr int DWV_MAXCAND = 2;           // more candidates than this: the map goes to the all-pixel kernel's list
                                          // (a candidate costs a wave ~1.5 us of serial float64 chains; 94 % of maps have 1)
@@ -912,23 +914,46 @@ __device__ __forceinline__ double dwv_col_chain(double t, int base, int T, const
   return c;
 }
 
-__global__ void decode_zero_count_kernel(int *count) {
-  if (threadIdx.x == 0) *count = 0;
+// ---- work list in the workspace (see the protocol above); every access agent-scope, relaxed
+__device__ __forceinline__ int wl_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wl_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wl_push(int *ws, int map) {          // one lane
+  const int i = __hip_atomic_fetch_add(ws, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  wl_store(ws + 4 + i, map + 1);
+}
+constexpr int WL_POLL_LIMIT = 2048;        // helper polls (~2 us apart) before it gives up: ~4 ms
+constexpr int WL_HELPERS = 64;             // helper workgroups per launch
+// one lane of a helper or of the last screening workgroup: the next listed map, or -1 when there is nothing (more) to do
+__device__ __forceinline__ int wl_pop(int *ws, bool helper, int n_screen) {
+  for (int polls = 0;;) {
+    const int done = wl_load(ws + 2);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);           // `done` is read BEFORE the counters it vouches for
+    const int t = wl_load(ws + 1), pushed = wl_load(ws + 0);
+    if (t < pushed) {
+      int expect = t;
+      if (__hip_atomic_compare_exchange_strong(ws + 1, &expect, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) {
+        int v = 0;
+        for (int w = 0; w < (1 << 20) && (v = wl_load(ws + 4 + t)) == 0; ++w) __builtin_amdgcn_s_sleep(2);
+        wl_store(ws + 4 + t, 0);
+        return v - 1;                                  // (-1 only if the writer vanished: nothing to decode)
+      }
+      continue;                                        // somebody else took it: look again
+    }
+    if (!helper || done >= n_screen || ++polls > WL_POLL_LIMIT) return -1;
+    __builtin_amdgcn_s_sleep(64);                      // 64 x 64 clocks ~ 2 us
+  }
 }
 
-template <int H, int W, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel(
-    const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
-    int K, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y, double in_w,
-    double in_h, DecodeOut o, int *__restrict__ slow_list) {
+template <int H, int W>
+__device__ __forceinline__ void wave_decode_map(
+    const int map, float *__restrict__ buf, const float *__restrict__ heatmaps, const float *prob, const float *vis,
+    const float *oks, const float *err, int B, int K, const double *__restrict__ taps, const int *__restrict__ radius,
+    double den_x, double den_y, double in_w, double in_h, DecodeOut o, int *__restrict__ ws) {
   using G = WaveGeom<H, W>;
   constexpr int HW = G::HW;
-  __shared__ __attribute__((aligned(16))) float lds[NWV][G::BUF];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int map = blockIdx.x * NWV + wave;
-  if (map >= B * K) return;                          // whole waves leave; nothing below synchronises across waves
+  const int lane = threadIdx.x & 63;
   const int k = map % K;
-  float *buf = lds[wave];
   const float *__restrict__ src = heatmaps + (size_t)map * HW;
   const int r = __builtin_amdgcn_readfirstlane(radius[k]);
   const double *__restrict__ wk = taps + (size_t)k * PP_MAX_TAPS;
@@ -976,6 +1001,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
     return;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the map is in LDS (this wave's own buffer)
+  if (finite && gmax > gmin) {
+    // early flat-map test: a clamped plateau shows as many pixels AT the map's maximum.  Such a map will not come out of
+    // the screen with <= DWV_MAXCAND candidates, so it is handed over now, before the float32 passes (a scheduling
+    // guess only: a wrong guess either way costs time, never the result)
+    int at_max = 0;
+#pragma unroll
+    for (int i = 0; i < G::NLD; ++i) {
+      const int e = 4 * (i * 64 + lane), y = e / W, x = e - y * W;
+      const float4 t = *reinterpret_cast<const float4 *>(buf + y * G::RS + x);
+      at_max += (t.x == gmax) + (t.y == gmax) + (t.z == gmax) + (t.w == gmax);
+    }
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) at_max += __shfl_xor(at_max, o_, 64);
+    if (at_max > 12) {
+      if (lane == 0) wl_push(ws, map);
+      return;
+    }
+  }
 
   DWS(1);
   int cand_r[(DWV_MAXCAND + 63) / 64];                       // candidate ci lives in lane ci % 64 (register, not LDS:
@@ -1034,8 +1077,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
   DWS(3);
   if (ncand > DWV_MAXCAND) {
     // Flat map (a clamped plateau: hundreds of exact ties and near-ties) or non-finite map (every pixel counts): not
-    // worth a wave's serial chains.  It goes on the list of the all-pixel float64 kernel that follows on the stream.
-    if (lane == 0) slow_list[1 + atomicAdd(slow_list, 1)] = map;
+    // worth a wave's serial chains.  It goes on the work list of the all-pixel float64 decode (whole workgroups).
+    if (lane == 0) wl_push(ws, map);
     return;
   }
   // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN).  Row chains on lanes 0..T-1, handed to the
@@ -1125,6 +1168,62 @@ __global__ __launch_bounds__(NWV * 64, NWV == 1 ? 2 : 3) void decode_wave_kernel
 #undef DWS
 }
 
+template <int H, int W, int NWV>
+constexpr __host__ __device__ int wave_kernel_image_bytes() {
+  constexpr int allpix = H * W * 8 + H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) * 4;
+  constexpr int waves = NWV * WaveGeom<H, W>::BUF * 4;
+  return ((waves > allpix ? waves : allpix) + 15) & ~15;
+}
+template <int H, int W, int NWV>
+constexpr int wave_kernel_lds_bytes() { return wave_kernel_image_bytes<H, W, NWV>() + NWV * (int)sizeof(Best) + 16; }
+
+// NWV waves (= maps) per screening workgroup; MINW = waves per SIMD the register budget is cut for.
+template <int H, int W, int NWV, int MINW>
+__global__ __launch_bounds__(NWV * 64, MINW) void decode_wave_kernel(
+    const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
+    int K, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y, double in_w,
+    double in_h, DecodeOut o, int *__restrict__ ws, int n_screen) {
+  using G = WaveGeom<H, W>;
+  // phase 1: one map per wave in its own buffer; phase 2: the same bytes hold the all-pixel image of a listed map
+  // (all LDS is dynamic: a static array in front of it would shift the 16-byte alignment of the images)
+  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+  float *lds = reinterpret_cast<float *>(dyn_lds);
+  Best *red = reinterpret_cast<Best *>(dyn_lds + wave_kernel_image_bytes<H, W, NWV>());
+  int &s_item = *reinterpret_cast<int *>(red + NWV);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool helper = (int)blockIdx.x >= n_screen;
+  bool pops = helper;                                       // does this workgroup take part in draining the list?
+  if (!helper) {
+    const int map = blockIdx.x * NWV + wave;
+    if (map < B * K)
+      wave_decode_map<H, W>(map, lds + wave * G::BUF, heatmaps, prob, vis, oks, err, B, K, taps, radius, den_x, den_y,
+                            in_w, in_h, o, ws);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's push (if any) is written through
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_item = __hip_atomic_fetch_add(ws + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_screen - 1;
+    __syncthreads();
+    pops = s_item != 0;                                     // the last screening workgroup: every push is in by now
+    __syncthreads();
+    if (!pops) return;                                      // everybody else: one atomic and out
+  }
+  for (;;) {
+    if (threadIdx.x == 0) s_item = wl_pop(ws, helper, n_screen);
+    __syncthreads();
+    const int it = s_item;
+    __syncthreads();
+    if (it < 0) break;
+    decode_lds_map<NWV * 64>(it, reinterpret_cast<char *>(lds), red, heatmaps, prob, vis, oks, err, B, K, H, W, taps,
+                             radius, den_x, den_y, in_w, in_h, o, nullptr);
+    __syncthreads();
+  }
+  // leavers = the helpers + the last screening workgroup: the only readers of the counters.  The last one out zeroes them.
+  if (threadIdx.x == 0 &&
+      __hip_atomic_fetch_add(ws + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - n_screen) {
+    wl_store(ws + 0, 0); wl_store(ws + 1, 0); wl_store(ws + 2, 0); wl_store(ws + 3, 0);
+  }
+}
+
 static size_t screen_lds_bytes(int H, int W) {
   return ((size_t)H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) + (size_t)H * W + DF_MAXCAND) * 4;
 }
@@ -1198,17 +1297,10 @@ static size_t lds_bytes(int H, int W) {
 }
 static bool fits_lds(int H, int W) { return lds_bytes(H, W) <= LDS_LIMIT; }
 static bool wave_geometry(int H, int W) { return (H == 64 && W == 48) || (H == 96 && W == 72); }
-// PP_DECODE_EXACT_ALL=1 forces the all-pixel float64 kernel (A/B runs and the equivalence test of the screened path)
-static bool getenv_flag(const char *name) {
-  const char *e = getenv(name);
-  return e && e[0] == '1';
-}
-static bool getenv_exact() { return getenv_flag("PP_DECODE_EXACT_ALL"); }
-
 }  // namespace pp
 
 extern "C" size_t pp_decode_workspace_bytes(int B, int K, int H, int W) {
-  if (pp::wave_geometry(H, W)) return ((size_t)B * K + 1) * sizeof(int);   // hand-over list of the wave-per-map path
+  if (pp::wave_geometry(H, W)) return ((size_t)B * K + 4) * sizeof(int);   // work list of the wave-per-map path (zeroed once by the caller)
   if (pp::fits_lds(H, W)) return 0;
   return (size_t)B * K * H * W * (sizeof(double) + sizeof(float));
 }
@@ -1218,7 +1310,7 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
                              const double *taps, const int *radius, double den_x, double den_y,
                              double in_w, double in_h, double *out_kpts, float *out_scores,
                              float *out_locs, float *out_aux, double *out_err, float *out_conv,
-                             double *out_packed, void *workspace, void *stream) {
+                             double *out_packed, void *workspace, int flags, void *stream) {
   using namespace pp;
   PP_REQUIRE(B >= 0 && K > 0 && H > 0 && W > 0, "pp_decode_f32: bad shape B=%d K=%d H=%d W=%d", B, K,
              H, W);
@@ -1233,36 +1325,35 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   // Measured (tools/decode_ab.py, one process, interleaved): 96x72 maps 699 vs 884 us per 128 x 133 maps (-21 %); 64x48
   // maps 24.3 vs 22.9 us at B = 64 and 236 vs 234 us at B = 1024 (a tie: both forms are bound by the latency of their
   // short barrier-separated phases, not by HBM, LDS or the FMA rate).  The screened form is the default where it
-  // wins (maps larger than 4096 pixels); PP_DECODE_SCREEN=1 forces it everywhere, PP_DECODE_EXACT_ALL=1 never.
-  // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288), when the caller passed the workspace
-  // pp_decode_workspace_bytes asks for (without one: the workgroup-per-map kernels below); PP_DECODE_WAVE=0 turns it
-  // off (A/B runs)
-  const char *wave_env = getenv("PP_DECODE_WAVE");
-  const bool wave_off = wave_env && wave_env[0] == '0';
-  if (!out_conv && !wave_off && !getenv_exact() && workspace && ((uintptr_t)heatmaps & 15) == 0 &&
+  // wins (maps larger than 4096 pixels); flag PP_DECODE_SCREEN forces it everywhere, PP_DECODE_ALL_PIXEL never.
+  // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288), when the caller passed the (zeroed)
+  // workspace pp_decode_workspace_bytes asks for (without one: the workgroup-per-map kernels below)
+  PP_REQUIRE((flags & ~(PP_DECODE_NO_WAVE | PP_DECODE_SCREEN | PP_DECODE_ALL_PIXEL)) == 0, "pp_decode_f32: bad flags %d", flags);
+  const bool exact_all = (flags & PP_DECODE_ALL_PIXEL) != 0;
+  if (!out_conv && !(flags & PP_DECODE_NO_WAVE) && !exact_all && workspace && ((uintptr_t)heatmaps & 15) == 0 &&
       ((uintptr_t)workspace & 3) == 0 && wave_geometry(H, W)) {
-    int *slow_list = reinterpret_cast<int *>(workspace);       // [0] = count, [1 ..] = maps left to the all-pixel kernel
-    hipLaunchKernelGGL(decode_zero_count_kernel, dim3(1), dim3(64), 0, s, slow_list);   // (a memset node costs 5 us)
-    if (H == 64)
-      hipLaunchKernelGGL((decode_wave_kernel<64, 48, 4>), dim3((unsigned)cdiv(maps, 4)), dim3(256), 0, s, heatmaps, prob,
-                         vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, slow_list);
-    else
-      hipLaunchKernelGGL((decode_wave_kernel<96, 72, 1>), dim3((unsigned)maps), dim3(64), 0, s, heatmaps, prob, vis, oks,
-                         err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, slow_list);
+    int *ws = reinterpret_cast<int *>(workspace);
+    auto launch = [&](auto kern, int nwv, int lds) -> int {
+      const int n_screen = cdiv(maps, nwv);
+      const int helpers = WL_HELPERS;
+      static thread_local unsigned long long attr_mask3[2] = {0, 0};
+      int dev3 = 0;
+      if (lds > 48 * 1024 && attr_needed(attr_mask3[H == 64 ? 0 : 1], dev3))
+        PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(n_screen + helpers)), dim3(nwv * 64), lds, s, heatmaps, prob, vis, oks, err,
+                         B, K, taps, radius, den_x, den_y, in_w, in_h, o, ws, n_screen);
+      return 0;
+    };
+    if (H == 64) {
+      if (launch(decode_wave_kernel<64, 48, 4, 3>, 4, wave_kernel_lds_bytes<64, 48, 4>())) return -1;
+    } else {
+      if (launch(decode_wave_kernel<96, 72, 5, 2>, 5, wave_kernel_lds_bytes<96, 72, 5>())) return -1;
+    }
     PP_CHECK_LAUNCH("decode_wave_kernel");
-    const size_t lds = lds_bytes(H, W);
-    static thread_local unsigned long long attr_mask3 = 0;
-    int dev3 = 0;
-    if (lds > 64 * 1024 && attr_needed(attr_mask3, dev3))
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_lds_list_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-    hipLaunchKernelGGL(decode_lds_list_kernel, dim3((unsigned)(maps < 256 ? maps : 256)), dim3(DEC_THREADS), lds, s,
-                       slow_list, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w, in_h, o);
-    PP_CHECK_LAUNCH("decode_lds_list_kernel");
     return 0;
   }
-  const bool want_screen = getenv_flag("PP_DECODE_SCREEN") || (long long)H * W > 4096;
-  if (!out_conv && want_screen && !getenv_exact() && screen_lds_bytes(H, W) <= SCREEN_DYN_LIMIT) {
+  const bool want_screen = (flags & PP_DECODE_SCREEN) || (long long)H * W > 4096;
+  if (!out_conv && want_screen && !exact_all && screen_lds_bytes(H, W) <= SCREEN_DYN_LIMIT) {
     const size_t lds = screen_lds_bytes(H, W);
     const int items = ((H + 3) / 4) * W;
     if (items <= 3 * DF_THREADS) {

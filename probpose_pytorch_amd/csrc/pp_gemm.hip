@@ -17,7 +17,8 @@
 // bf16: v_mfma_f32_16x16x32_bf16; fp32 (parity mode): v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 FMA chain;
 // fp8 (e4m3): v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, dequantised per column in the epilogue.
 // Epilogues: bias / row bias / GELU / ReLU / in-place fp32 residual / NCHW heatmap store, the C tile staged
-// through the dead K-loop buffers and stored as whole rows; optional LayerNorm producer / consumer modes.
+// through the dead K-loop buffers and stored as whole rows.  Forms: per-launch (gemm_kernel: plain, ping-pong order,
+// wave-specialised producers), persistent stream (gemm_persist_kernel), two workgroups per CU (gemm_duo_kernel).
 #include <type_traits>
 #include <utility>
 
@@ -102,10 +103,6 @@ struct GemmParams {
 // prefetch behind the MFMAs.  The asm DMA is invisible to its wait-count bookkeeping; completion is
 // enforced by the explicit s_waitcnt vmcnt(0) + barrier that ends each K-step.
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_off_uniform) {
-#ifdef PP_ABL_NODMA   // ablation builds only (tools/build_lab.sh): no staging traffic, results are garbage
-  asm volatile("" ::"v"(gsrc), "s"(lds_off_uniform));
-  return;
-#endif
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -280,13 +277,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + sw * PA * 1024);
     st_ldsB = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + sw * PB * 1024);
     st_koff = (size_t)kt * ROW_BYTES;
-#ifdef PP_GEMM_KROT   /* lab: column tile tn walks K from K-tile (tn * PP_GEMM_KROT) % nkt, so that the workgroups that
-                         share an A row-panel do not ask for the same lines at the same moment */
-    if constexpr (!GATHER) {
-      const int ktr = kt + (tn * PP_GEMM_KROT) % nkt;
-      st_koff = (size_t)(ktr >= nkt ? ktr - nkt : ktr) * ROW_BYTES;
-    }
-#endif
     if constexpr (GATHER) {
       const int k0 = kt * BK;
       const int seg = k0 / p.seg_len;
@@ -419,32 +409,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
               }(std::make_integer_sequence<int, PIECES>{});
             }
             if constexpr (sizeof(T) == 2) {
-#ifdef PP_EXP_SETPRIO
-              __builtin_amdgcn_s_setprio(1);
-#endif
-#if defined(PP_ABL_NOMMA)     // ablation: fragment reads stay (kept alive), no matrix work
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                const unsigned k0 = bf[j].x ^ af[i].x, k1 = bf[j].y ^ af[i].y, k2 = bf[j].z ^ af[i].z,
-                               k3 = bf[j].w ^ af[i].w;
-                asm volatile("" ::"v"(k0), "v"(k1), "v"(k2), "v"(k3));
-              }
-#elif defined(PP_ABL_NOLDS)   // ablation: matrix work on whatever the registers hold, no fragment reads
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                bf16x8 za = {}, zb = {};
-                asm volatile("" : "+v"(za), "+v"(zb));
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(zb, za, acc[i][j], 0, 0, 0);
-              }
-#else
 #pragma unroll
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     *reinterpret_cast<bf16x8 *>(&bf[j]), *reinterpret_cast<bf16x8 *>(&af[i]), acc[i][j], 0, 0, 0);
-#endif
-#ifdef PP_EXP_SETPRIO
-              __builtin_amdgcn_s_setprio(0);
-#endif
             } else if constexpr (sizeof(T) == 1) {
               // fp8 (e4m3): the 16-B chunk holds 16 consecutive k = two 8-byte MFMA operands; step h takes half h
               // of every lane's chunk (k slots 16 * (4s + fq) + 8h .. +7: the same permutation on both operands).
@@ -495,9 +463,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     }
   };
   auto pp_mma = [&]() {
-#ifdef PP_MMA_PRIO
-    __builtin_amdgcn_s_setprio(PP_MMA_PRIO);
-#endif
     if constexpr (ES == 1) {
       typedef int i32x8 __attribute__((ext_vector_type(8)));
       constexpr int UNIT = 0x7f7f7f7f;
@@ -533,13 +498,10 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
           }
         }
     }
-#ifdef PP_MMA_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   // ---- pipeline fill first: the DMA of the first STAGES-1 K-tiles is in flight while the epilogue
-  // operands below (residual / bias / LayerNorm statistics) are fetched and reduced.  Those loads are
+  // operands below (residual / row bias / bias) are fetched.  Those loads are
   // YOUNGER than the fill, so the first counted wait of the K-loop over-waits (it also retires tile 1):
   // safe, and tile 1 was issued together with tile 0 anyway.
   if constexpr (NWP == 0) {
@@ -667,85 +629,8 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
   ct_loop0 = __builtin_amdgcn_s_memtime();
   __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-  if constexpr (NWP > 0 && PINGPONG) {
-    // ---- wave-specialised form, software-pipelined consumer (one consumer wave per SIMD: nothing else hides its
-    // LDS latency).  MFMA groups of TN (one activation row-tile x all weight column tiles); while group g runs,
-    // the activation fragment of group g + 1 and a share of the NEXT k-step's weight fragments are already being
-    // read.  The barrier that publishes K-tile kt + 1 (and tells the producers that K-tile kt has been read: they
-    // overwrite its buffer next) sits in front of the LAST group of K-tile kt, right after the last fragment read
-    // of that tile has landed, so the first fragments of K-tile kt + 1 are in flight under that group's MFMAs.
-    static_assert(ES == 2, "pipelined consumer: bf16");
-    constexpr int BPG = (TN + TM - 1) / TM;   // next-step weight fragments read per group
-    uint4 Bc[TN], Bn[TN], Ac, An;
-    auto ldA = [&](int buf, int s, int i) {
-      return *reinterpret_cast<const uint4 *>(smem + buf * STAGE_BYTES + pp_offA[s] + i * 16 * ROW_BYTES);
-    };
-    auto ldB = [&](int buf, int s, int j) {
-      return *reinterpret_cast<const uint4 *>(smem + buf * STAGE_BYTES + pp_offB[s] + j * 16 * ROW_BYTES);
-    };
-    auto group = [&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8 *>(&Bc[j]),
-                                                            *reinterpret_cast<bf16x8 *>(&Ac), acc[i][j], 0, 0, 0);
-    };
-    auto ktile = [&](int buf, int nb, auto lastc) {
-      constexpr bool LAST = decltype(lastc)::value;
-      // k-step 0: read the k-step-1 fragments of this K-tile underneath
-      [&]<int... I>(std::integer_sequence<int, I...>) {
-        ([&] {
-          constexpr int i = I;
-          An = (i + 1 < TM) ? ldA(buf, 0, i + 1) : ldA(buf, 1, 0);
-#pragma unroll
-          for (int j = i * BPG; j < (i + 1) * BPG && j < TN; ++j) Bn[j] = ldB(buf, 1, j);
-          __builtin_amdgcn_sched_barrier(0);
-          group(std::integral_constant<int, i>{});
-          __builtin_amdgcn_sched_barrier(0);
-          Ac = An;
-        }(), ...);
-      }(std::make_integer_sequence<int, TM>{});
-#pragma unroll
-      for (int j = 0; j < TN; ++j) Bc[j] = Bn[j];
-      // k-step 1: the last group carries the barrier and the first reads of the next K-tile
-      [&]<int... I>(std::integer_sequence<int, I...>) {
-        ([&] {
-          constexpr int i = I;
-          if constexpr (i + 1 < TM) {
-            An = ldA(buf, 1, i + 1);
-          } else if constexpr (!LAST) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            An = ldA(nb, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) Bn[j] = ldB(nb, 0, j);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          group(std::integral_constant<int, i>{});
-          __builtin_amdgcn_sched_barrier(0);
-          Ac = An;
-        }(), ...);
-      }(std::make_integer_sequence<int, TM>{});
-      if constexpr (!LAST) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Bc[j] = Bn[j];
-      }
-    };
-    __builtin_amdgcn_s_barrier();                       // K-tile 0 has landed
-    __builtin_amdgcn_sched_barrier(0);
-    Ac = ldA(0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) Bc[j] = ldB(0, 0, j);
-    An = Ac;
-    int buf = 0;
-    for (int kt = 0; kt + 1 < nkt; ++kt) {
-      const int nb = buf + 1 == STAGES ? 0 : buf + 1;
-      ktile(buf, nb, std::false_type{});
-      buf = nb;
-    }
-    ktile(buf, 0, std::true_type{});
-  } else if constexpr (NWP > 0) {
+  if constexpr (NWP > 0) {
+    static_assert(!PINGPONG, "the ping-pong order is a form of the non-specialised kernel");
     // ---- wave-specialised K-loop: same barrier protocol, the two halves of each iteration on
     // different waves.  Every wave executes exactly nkt barriers.
     {
@@ -770,9 +655,7 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
   // (found in the round-1 kernel's ISA: the counted vmcnt(PIECES) was followed by a compiler vmcnt(0)).
   // Retire them once here with a wait the compiler models: from now on only DMA pieces are outstanding and
   // the loop keeps nothing but the counted waits.  Cost: the first iteration also waits for K-tile 1.
-#ifndef PP_NO_PRELOOP_WAIT
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
-#endif
 #ifdef PP_GEMM_STAMPS
   t_pro_v = stamp();
 #endif
@@ -869,12 +752,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
       pp_mma();
     }
   } else {
-#ifdef PP_YOUNG_PRIO
-  // static priority for the second-dispatched half of an 8-wave workgroup (the arbitration losers on every SIMD)
-  if constexpr (NW == 8) {
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(PP_YOUNG_PRIO);
-  }
-#endif
   int buf = 0, kt = 0;
   // steady state: every iteration prefetches tile kt + STAGES - 1 (one code path in the loop body,
   // so the accumulators stay in place across iterations)
@@ -915,9 +792,6 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
     PP_ACC(c_comp, tc, te);
     if (++buf == STAGES) buf = 0;
   }
-#ifdef PP_YOUNG_PRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
   }
   }
   PP_STAMP(t_loop);
@@ -1045,6 +919,16 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
           const int r = rows_lds[lr];
           if (r < 0 || cc >= ncols16) continue;
           const uint4 v = *reinterpret_cast<const uint4 *>(smem + lr * CS + cc * 16);
+          if constexpr (OES == 2) {
+            if (epi & PP_EPI_HEADMAJOR) {
+              // qkv projection written head-major, [3][heads][M][head_dim]: one head's rows are contiguous for the
+              // attention kernel (a 160-byte head row at a 7 680-byte stride touches 2 - 3 cache lines, ViT-H)
+              const int n = n0 + pass * PBN + cc * 8, Cc = p.hm_K * p.hm_HW;
+              const int which = n / Cc, rem = n - which * Cc, head = rem / p.hm_HW, d = rem - head * p.hm_HW;
+              *reinterpret_cast<uint4 *>(Cb + ((((size_t)which * p.hm_K + head) * p.M + r) * p.hm_HW + d) * 2) = v;
+              continue;
+            }
+          }
           *reinterpret_cast<uint4 *>(Cb + ((size_t)r * p.ldc + n0 + pass * PBN) * OES + cc * 16) = v;
         }
       }
@@ -1143,25 +1027,34 @@ __global__ __launch_bounds__(64 * (WGM * WGN + NWP), (WGM * WGN + NWP + 3) / 4 <
 // ---------------------------------------------------------------------------------------------------------
 // Persistent form of the 192x192 / 8-wave / 3-stage configuration for the plain bf16 -> bf16 layers (qkv, fc1).
 //
-// Measured on the per-launch form (tools/gemm_timeline.py, ViT-B bs 64): a workgroup lives 17-19 us per tile, of
-// which the K-loop is only 11.6 us; 2.6 us go to the pipeline fill (address set-up, the first two K-tiles' DMA
-// latency) and 3-5 us to the epilogue (GELU + 18.9 MB per round stored by all 256 CUs in the same phase), and one
-// workgroup per CU means nothing else runs on the CU meanwhile.  Here one workgroup per CU walks its tiles back to
-// back as ONE continuous stream of K-tiles through the LDS ring: the DMA of the next tile's first K-tiles is issued
-// during the current tile's last ones (no fill between tiles), and a finished tile stays in 72 registers
-// (fp32) and is biased / activated / packed / stored in 9 slices underneath the first 9 K-tiles of the NEXT tile
-// (VALU and the store path beside the matrix pipe).  The bias of a tile comes through LDS by one small DMA per
-// tile (no compiler-visible global loads inside the stream: hipcc would drain the DMA ring for them).  Only the
-// last tile of a workgroup pays an un-overlapped epilogue.  Stores are issued at the head of an iteration, before
-// that iteration's DMA pieces, so the counted vmcnt(PIECES) never waits for anything younger than one K-tile.
+// Measured on the per-launch form (tools/gemm_timeline.py, ViT-B bs 64, round 3): a workgroup of qkv lives 17.6 us, of
+// which the K-loop is 12.0; 2.9 us go to the pipeline fill -- every CU of the chip asks for its first two K-tiles in
+// the same microsecond, a cold burst of ~25 MB -- 2.7 us to the epilogue (4.7 with GELU), and 0.4 us pass between one
+// workgroup's end and the next one's start on a CU.  With 3 (qkv) or 4 (fc1) tiles per CU the fill + gap are paid 3 - 4
+// times per launch.  Here ONE workgroup per CU walks its tiles as ONE continuous stream of K-tiles through the LDS
+// ring: the DMA of the next tile's first two K-tiles is issued during the current tile's last two iterations, so they
+// land underneath the epilogue, which runs right away out of the accumulators: bias / activation / bf16 -> the ring
+// buffer the last K-tile was read from (the other two hold the next tile's K-tiles) in two column passes -> whole-row
+// 16-byte stores.  (Round 2 built this stream with the epilogue DEFERRED into the next tile's K-loop, 9 slices of
+// VALU + 8-byte stores between the MFMA groups: it tied the per-launch form, the K-loop is issue-bound and took the
+// slices at full price.  Here the K-loop is exactly the per-launch form's.)
+// No compiler-visible global load or store exists in this kernel: the bias arrives by one small DMA per tile, the C
+// rows leave through inline-asm stores, so hipcc places no vmcnt wait of its own and the counted waits below are the
+// only ones.  vmcnt is in order: the first wait after an epilogue also retires all but PIECES of its stores.
 // ---------------------------------------------------------------------------------------------------------
+template <int ACT>   // 0 none, 1 GELU, 2 ReLU (compile-time: see lds_epilogue of gemm_kernel)
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int vblocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef PP_GEMM_TIMELINE
+  const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+  unsigned long long rt_loop0 = 0, rt_loop1 = 0, ct_loop0 = 0, ct_loop1 = 0, ct_epi = 0;
+#endif
   constexpr int BM = 192, BN = 192, WGN = 4, STAGES = 3, BK = 64;
   constexpr int PA = 3, PB = 3, PIECES = PA + PB, TM = 6, TN = 3;
   constexpr int A_BYTES = BM * ROW_BYTES, STAGE_BYTES = (BM + BN) * ROW_BYTES;
   constexpr int BIAS_OFF = STAGES * STAGE_BYTES, BIAS_SLOT = BN * 4;   // 3 slots of 192 floats behind the ring
-  constexpr int NSLICE = TM * TN / 2;                                    // deferred-epilogue slices (2 tiles each)
+  constexpr int CPASS = 2, PBM = BM / CPASS, CS = BN * 2 + 16, CPR = BN * 2 / 16;   // C staging: 96 whole rows per pass
+  static_assert(PBM * CS <= STAGE_BYTES && PBM == BM / 2, "a C pass (the rows of one wave row) must fit one ring buffer");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave - wm * WGN;
   const int prow = lane >> 3, pchunk = lane & 7, frow = lane & 15, fq = lane >> 4;
@@ -1193,10 +1086,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
       if (decode(vb, tm, tn)) return vb;
     return -1;
   };
-  int ntiles = 0;
-  for (int vb = next_valid((int)blockIdx.x); vb >= 0; vb = next_valid(vb + (int)gridDim.x)) ++ntiles;
-  if (ntiles == 0) return;
-  const int total = ntiles * nkt;
+  if (next_valid((int)blockIdx.x) < 0) return;
 
   const char *zero_line = (const char *)g_zero_page +
                           ((((blockIdx.x * 29 + wave) * 8 + prow) & 7) * 128 + pchunk * 16) +
@@ -1231,7 +1121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
   size_t st_koff = 0;
   // Every iteration of the stream stages one K-tile, so that every iteration is the same straight-line code and
   // the counted vmcnt(PIECES) holds to the end: once the workgroup's tiles are exhausted (the last two
-  // iterations) the pieces re-read the last K-tile into the buffer nobody will read again.
+  // iterations) the pieces re-read the last K-tile into the two buffers nobody will read again.
   auto stage_begin = [&](int buf) __attribute__((always_inline)) {      // latch (s_vb, s_kt) for the pieces of this iteration
     const bool st_live = s_vb >= 0;
     st_ldsA = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + wave * PA * 1024);
@@ -1276,14 +1166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
     stage_end();
   };
 
-  // acc: the tile being accumulated.  fin: the finished tile awaiting its activation + store, held as packed bf16 of
-  // (accumulator + bias) -- 36 registers instead of 72 (two fp32 tiles + fragments do not fit 256 VGPRs without
-  // spills, and a spill reload inside the stream costs a vmcnt(0)).  For layers without an activation this is the
-  // final value; with GELU the activation is applied to the bf16-rounded pre-activation (one extra rounding of
-  // <= 2^-9 relative on its argument, same order as the output's own bf16 rounding).
   f32x4 acc[TM][TN];
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 fin[TM][TN];
   constexpr int GROUPS = 2 * TM;
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char *ldsA = smem + buf * STAGE_BYTES;
@@ -1325,57 +1208,86 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
     }(std::make_integer_sequence<int, 2>{});
   };
 
-  // ---- deferred epilogue of the finished tile: accumulator tile q = (i, j), q a compile-time constant.
-  // The store is inline asm on purpose: hipcc counts its own stores in vmcnt and protects their data registers with
-  // vmcnt(N) waits that know nothing of the DMA pieces -- in the loop they drained the whole ring (seen in the ISA).
-  int prev_m0 = 0, prev_n0 = 0;
-  bool have_prev = false;
-  bf16_t *Cb = reinterpret_cast<bf16_t *>(p.C);
-  auto half_slice = [&](auto qc) __attribute__((always_inline)) {
-    constexpr int q = decltype(qc)::value;
-    constexpr int i = q / TN, j = q % TN;
-    int m = prev_m0 + wm * (BM / 2) + i * 16 + frow;
-    // opaque: the 18 store addresses are loop-invariant inside a tile and LICM would hoist all of them (36
-    // registers + predicates) out of the K-loop, pushing the kernel into scratch; a volatile asm is never hoisted
-    asm volatile("" : "+v"(m));
-    const int nl = wn * (BN / WGN) + j * 16 + fq * 4;
-    unsigned lo = fin[i][j].x, hi = fin[i][j].y;
-    if (epi & PP_EPI_GELU) {
-      float v[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
-                    __uint_as_float(hi & 0xffff0000u)};
-      gelu4<bf16_t>(v);
-      lo = pack_bf16x2(v[0], v[1]);
-      hi = pack_bf16x2(v[2], v[3]);
-    }
-    if (m < p.M && prev_n0 + nl < p.N) {
-      const unsigned long long pk = (unsigned long long)lo | ((unsigned long long)hi << 32);
-      bf16_t *dst = Cb + (size_t)m * p.ldc + prev_n0 + nl;
-#ifdef PP_P13_NOSTORE
-      asm volatile("" ::"v"(dst), "v"(pk) : "memory");
-#else
-      asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(pk) : "memory");
-#endif
-    }
-  };
-  auto run_slice = [&](int sl) __attribute__((always_inline)) {   // wave-uniform sl: one of NSLICE straight-line copies
-    [&]<int... SL>(std::integer_sequence<int, SL...>) {
-      ([&] {
-        if (sl == SL) {
-          half_slice(std::integral_constant<int, 2 * SL>{});
-          half_slice(std::integral_constant<int, 2 * SL + 1>{});
+  // ---- epilogue of the tile just accumulated, through ring buffer `buf` (the one its last K-tile was read from: no
+  // DMA targets it until the next iteration of the stream, the other two buffers hold the next tile's first K-tiles).
+  constexpr int ST_PER_PASS = (PBM * CPR + 511) / 512;           // store instructions per wave and row pass
+  constexpr int ST_PER_TILE = CPASS * ST_PER_PASS;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long c_base = (unsigned long long)p.C;
+  // raw buffer descriptor of C (stride 0, byte-granular range check): offsets at or beyond M * ldc * 2 bytes are dropped
+  const i32x4 c_srd = {(int)(unsigned)c_base, (int)(unsigned)((c_base >> 32) & 0xFFFFu),
+                       (int)(unsigned)((size_t)p.M * p.ldc * 2), 0x00020000};
+  auto epilogue = [&](int buf, int m0, int n0, int slot) __attribute__((always_inline)) {
+    char *cst = smem + buf * STAGE_BYTES;
+    // every wave first turns its accumulators into packed bf16 (bias, activation: the VALU part runs on all 8 waves at
+    // once), then the two wave rows take turns through the one free ring buffer: 96 whole rows (384 B each) per pass
+    uint2 pk[TM][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (epi & PP_EPI_BIAS)
+        b4 = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + slot * BIAS_SLOT + (wn * (BN / WGN) + j * 16 + fq * 4) * 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
+        if constexpr (ACT == 1) gelu4<bf16_t>(v);
+        if constexpr (ACT == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-      }(), ...);
-    }(std::make_integer_sequence<int, NSLICE>{});
+        pk[i][j].x = pack_bf16x2(v[0], v[1]);
+        pk[i][j].y = pack_bf16x2(v[2], v[3]);
+      }
+    }
+    const int ncols16 = max(0, min(CPR, (p.N - n0) * 2 / 16));
+#pragma unroll
+    for (int pass = 0; pass < CPASS; ++pass) {
+      __syncthreads();                   // every wave has finished reading the K-tile (pass 0) / storing the previous pass
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            *reinterpret_cast<uint2 *>(cst + (i * 16 + frow) * CS + (wn * (BN / WGN) + j * 16 + fq * 4) * 2) = pk[i][j];
+      }
+      __syncthreads();
+      // EXACTLY ST_PER_PASS store instructions per wave and pass, whatever the tile's edges: rows / columns outside the
+      // matrix get an out-of-range buffer offset (the descriptor's range check drops them) instead of a branch around
+      // the store, because the counted waits of the next tile's first iterations rely on the number (see the stream)
+#pragma unroll
+      for (int it = 0; it < ST_PER_PASS; ++it) {
+        const int c = tid + it * 512;
+        const int lr = c / CPR, cc = c - lr * CPR;
+        const int row = m0 + pass * PBM + lr;
+        const bool ok = c < PBM * CPR && row < p.M && cc < ncols16;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(cst + (c < PBM * CPR ? lr * CS + cc * 16 : 0));
+        unsigned off = 0xFFFFFFF0u;
+        if (ok) {
+          if (epi & PP_EPI_HEADMAJOR) {          // [3][heads][M][head_dim], see gemm_kernel
+            const int n = n0 + cc * 8, Cc = p.hm_K * p.hm_HW;
+            const int which = n / Cc, rem = n - which * Cc, head = rem / p.hm_HW, d = rem - head * p.hm_HW;
+            off = (unsigned)(((((size_t)which * p.hm_K + head) * p.M + row) * p.hm_HW + d) * 2);
+          } else {
+            off = (unsigned)(((size_t)row * p.ldc + n0 + cc * 8) * 2);
+          }
+        }
+        // invisible to hipcc's vmcnt bookkeeping on purpose (a compiler-counted store ahead of the K-loop's back edge
+        // makes it guard the loop with vmcnt(0), which drains the DMA ring every K-tile)
+        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(off), "s"(c_srd) : "memory");
+      }
+    }
   };
 
   // ---- the stream: fill two K-tiles, then one identical iteration per K-tile, tile after tile
-#ifdef PP_GEMM_STAMPS
-  unsigned long long c_wait = 0, c_bar = 0, c_stage = 0, c_comp = 0, c_end = 0;
-#endif
-  PP_STAMP(t_begin);
   stage_all(0);
   stage_all(1);
-  int buf = 0, c_slot = 0;
+#ifdef PP_GEMM_TIMELINE
+  rt_loop0 = __builtin_amdgcn_s_memrealtime();
+  ct_loop0 = __builtin_amdgcn_s_memtime();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+  int buf = 0, c_slot = 0, post_store = 0;
   for (int t_vb = next_valid((int)blockIdx.x); t_vb >= 0; t_vb = next_valid(t_vb + (int)gridDim.x)) {
     int tm, tn;
     decode(t_vb, tm, tn);
@@ -1383,65 +1295,55 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(GemmParams p, int 
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int last = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-      PP_STAMP(ta);
-      wait_vmcnt<PIECES>();
+      // vmcnt counts loads, LDS-DMA and stores together, in issue order.  Right after an epilogue the queue of a wave
+      // reads [K-tile 0'] [K-tile 1'] [ST_PER_TILE stores]: retiring K-tile 0' must not wait for the stores behind it
+      // (their acknowledgements take microseconds when every CU writes), so the first two waits of a tile leave the
+      // stores outstanding as well; from the third iteration on the stores are older than what is waited for.
+      if (post_store > 0) {
+        wait_vmcnt<PIECES + ST_PER_TILE>();
+        --post_store;
+      } else {
+        wait_vmcnt<PIECES>();
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PP_STAMP(tb);
       __builtin_amdgcn_s_barrier();
-      PP_STAMP(tc);
-#ifndef PP_P13_NOSLICE
-      if (have_prev && kt < NSLICE) run_slice(kt);
-#endif
       __builtin_amdgcn_sched_barrier(0);
-      PP_STAMP(td);
       int nb = buf + STAGES - 1;
       if (nb >= STAGES) nb -= STAGES;
       stage_begin(nb);
       compute(buf);
-      PP_STAMP(te);
       stage_end();
-      PP_STAMP(tf);
-      PP_ACC(c_wait, ta, tb);
-      PP_ACC(c_bar, tb, tc);
-      PP_ACC(c_stage, tc, td);
-      PP_ACC(c_comp, td, te);
-      PP_ACC(c_end, te, tf);
+      last = buf;
       if (++buf == STAGES) buf = 0;
     }
-    if (have_prev)
-      for (int sl = min(nkt, NSLICE); sl < NSLICE; ++sl) run_slice(sl);
-    // tile boundary: accumulators + bias -> packed bf16 (ReLU commutes with the rounding and is applied here)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (epi & PP_EPI_BIAS)
-        b4 = *reinterpret_cast<const float4 *>(smem + BIAS_OFF + c_slot * BIAS_SLOT +
-                                               (wn * (BN / WGN) + j * 16 + fq * 4) * 4);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float v0 = acc[i][j][0] + b4.x, v1 = acc[i][j][1] + b4.y, v2 = acc[i][j][2] + b4.z, v3 = acc[i][j][3] + b4.w;
-        if (epi & PP_EPI_RELU) {
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-        }
-        fin[i][j] = u32x2{pack_bf16x2(v0, v1),
-                          pack_bf16x2(v2, v3)};
-      }
-    }
-    prev_m0 = tm * BM; prev_n0 = tn * BN; have_prev = true;
+#ifdef PP_GEMM_TIMELINE
+    const unsigned long long ce0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    epilogue(last, tm * BM, tn * BN, c_slot);
+#ifdef PP_GEMM_TIMELINE
+    ct_epi += __builtin_amdgcn_s_memtime() - ce0;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    post_store = 2;
     c_slot = c_slot == 2 ? 0 : c_slot + 1;
   }
-  PP_STAMP(t_loop);
+#ifdef PP_GEMM_TIMELINE
+  rt_loop1 = __builtin_amdgcn_s_memrealtime();
+  ct_loop1 = __builtin_amdgcn_s_memtime();
+#endif
   wait_vmcnt<0>();      // the dummy pieces of the last two iterations must not outlive the workgroup's LDS allocation
-  // the last tile of this workgroup: nothing left to hide its epilogue under
-  for (int sl = 0; sl < NSLICE; ++sl) run_slice(sl);
-#ifdef PP_GEMM_STAMPS
+#ifdef PP_GEMM_TIMELINE
   if ((p.epilogue & (1 << 30)) && lane == 0) {
-    PP_STAMP(t_end);
+    const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
     unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
                             ((size_t)blockIdx.x * 8 + wave) * 8;
-    o[0] = c_end; o[1] = c_wait; o[2] = c_bar; o[3] = c_stage; o[4] = c_comp;
-    o[5] = t_end - t_loop; o[6] = t_end - t_begin; o[7] = t_begin;
+    o[0] = rt_entry; o[1] = rt_loop0; o[2] = rt_loop1; o[3] = rt_end;
+    o[4] = __builtin_amdgcn_s_getreg(63492);
+    o[5] = __builtin_amdgcn_s_getreg(63508);
+    o[6] = ct_loop1 - ct_loop0 + 1; o[7] = ct_epi;      // stream cycles, of which epilogues
   }
 #endif
 }
@@ -1733,6 +1635,13 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
              "+11..16 us per fused GEMM against the 12 us LayerNorm launch they replace");
   if (a->epilogue & PP_EPI_HEATMAP)
     PP_REQUIRE(a->hm_K >= a->N && a->hm_HW > 0 && a->hm_temperature != 0.f, "pp_gemm: bad heatmap epilogue");
+  if (a->epilogue & PP_EPI_HEADMAJOR)
+    PP_REQUIRE(a->dtype == PP_BF16 && a->hm_K > 0 && a->hm_HW > 0 && a->hm_HW % 8 == 0 && a->N == 3 * a->hm_K * a->hm_HW &&
+                   a->ldc == a->N && (a->N & 7) == 0 && ((uintptr_t)a->C & 15) == 0 && !a->out_rowmap &&
+                   a->batch <= 1 && a->splitk <= 1 && a->tile != 14 &&
+                   !(a->epilogue & (PP_EPI_OUT_F32 | PP_EPI_HEATMAP | PP_EPI_RESIDUAL | PP_EPI_FUSE_FINAL | PP_EPI_OUT_FP8)),
+               "pp_gemm: PP_EPI_HEADMAJOR serves the bf16 qkv projection: N = 3 * heads (hm_K) * head_dim (hm_HW), head_dim a "
+               "multiple of 8, C 16-byte aligned, a plain single launch (not tile 14)");
   if (a->epilogue & PP_EPI_FUSE_FINAL) {
     PP_REQUIRE(a->dtype == PP_BF16 && a->N == 256 && a->final_w && a->final_b && a->hm_K > 0 && a->hm_K <= 32 &&
                    a->hm_HW > 0 && a->hm_temperature != 0.f && (a->tile == 9 || a->tile == 0) &&
@@ -1757,6 +1666,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   p.strideBias = a->strideBias; p.strideRowoff = a->strideRowoff; p.strideRowmap = a->strideRowmap;
   p.splitk = a->splitk > 1 ? a->splitk : 1;
   p.strideA_k = a->strideA_k; p.strideW_k = a->strideW_k; p.strideC_k = a->strideC_k; p.strideRowoff_k = a->strideRowoff_k;
+  if (a->epilogue & PP_EPI_HEADMAJOR) { p.hm_K = a->hm_K; p.hm_HW = a->hm_HW; }
   if (p.splitk > 1) {
     PP_REQUIRE(a->epilogue == PP_EPI_OUT_F32 && a->dtype != PP_FP8 && !a->out_rowmap,
                "pp_gemm: split-K launches write plain f32 partials (epilogue must be PP_EPI_OUT_F32 alone)");
@@ -1784,7 +1694,8 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
   // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 14, "pp_gemm: bad tile selector %d", a->tile);
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 14 && a->tile != 11 && a->tile != 12,
+             "pp_gemm: bad tile selector %d (11 / 12: round-2 experiments, removed)", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
     return (tiles + slots - 1) / slots;
@@ -1808,16 +1719,12 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     }
   }
   const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12 || cfg == 13 || cfg == 14) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
+  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 13 || cfg == 14) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   dim3 grid;
   auto set_grid = [&](int c) {   // c = tile configuration; tiles_m / tiles_n are set
-#ifdef PP_GEMM_RN_WIDE   /* lab: XCD blocks as wide as the whole N (A row-panels cross the fabric once) */
-    const int rn_ = std::min(PP_GEMM_RN_WIDE, p.tiles_n);
-#else
     const int rn_ = std::min((c >= 3) ? 4 : 8, p.tiles_n);
-#endif
     const long long nblk = (long long)cdiv(p.tiles_m, 8) * cdiv(p.tiles_n, rn_);
     p.rn = rn_;
     p.blocked = nblk >= 16 ? 1 : 0;
@@ -1832,6 +1739,9 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
                          ? 1
                          : 0;
   }
+  if (a->epilogue & PP_EPI_FUSE_FINAL)
+    PP_REQUIRE(p.lds_epilogue && vec, "pp_gemm: PP_EPI_FUSE_FINAL runs inside the LDS epilogue: C must be 16-byte aligned "
+                                      "(and N = ldc = 256)");
   hipStream_t s = (hipStream_t)stream;
   if (cfg == 14) {
     // duo form (gemm_duo_kernel): plain bf16 layers (K a multiple of 64 like every bf16 tile; it stages 32-deep K-tiles)
@@ -1855,8 +1765,10 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   if (cfg == 13) {
     // persistent 192x192 form (gemm_persist_kernel): plain bf16 -> bf16 layers only
     PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && p.lds_epilogue && batch == 1 &&
-                   !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | (1 << 30))),
-               "pp_gemm: tile 13 (persistent) serves plain bf16 -> bf16 GEMMs with bias / GELU / ReLU epilogues only");
+                   !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | PP_EPI_HEADMAJOR | (1 << 30))) &&
+                   (unsigned long long)a->M * a->ldc * 2 < 0xFFFFFFF0ull,
+               "pp_gemm: tile 13 (persistent) serves plain bf16 -> bf16 GEMMs with bias / GELU / ReLU epilogues only "
+               "(C below 4 GiB: its rows leave through 32-bit buffer offsets)");
     static int ncu = 0;
     if (ncu == 0) {
       int dev = 0, n = 0;
@@ -1870,10 +1782,17 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     constexpr int lds = 3 * (192 + 192) * ROW_BYTES + 3 * 192 * 4;
     static thread_local unsigned long long attr_mask = 0;
     int dev_ = 0;
-    if (attr_needed(attr_mask, dev_))
-      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_persist_kernel),
+    if (attr_needed(attr_mask, dev_)) {
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_persist_kernel<0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gemm_persist_kernel, dim3(wgs), dim3(512), lds, s, p, vblocks);
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_persist_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_persist_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    if (a->epilogue & PP_EPI_GELU) hipLaunchKernelGGL(gemm_persist_kernel<1>, dim3(wgs), dim3(512), lds, s, p, vblocks);
+    else if (a->epilogue & PP_EPI_RELU) hipLaunchKernelGGL(gemm_persist_kernel<2>, dim3(wgs), dim3(512), lds, s, p, vblocks);
+    else hipLaunchKernelGGL(gemm_persist_kernel<0>, dim3(wgs), dim3(512), lds, s, p, vblocks);
     PP_CHECK_LAUNCH("gemm_persist_kernel");
     return 0;
   }
@@ -1903,12 +1822,10 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   } while (0)
   const bool gather = a->rowoff != nullptr;
 #ifdef PP_GEMM_LAB   // experiment builds (tools/build_lab.sh): only the plain bf16 192x192 forms, compiles in seconds
-  if (a->dtype != PP_BF16 || gather || !vec || !(cfg == 3 || cfg == 6 || cfg == 10 || cfg == 11 || cfg == 12))
-    return fail("pp_gemm (lab build): only plain bf16 tiles 3, 6, 10, 11 and 12");
+  if (a->dtype != PP_BF16 || gather || !vec || !(cfg == 3 || cfg == 6 || cfg == 10))
+    return fail("pp_gemm (lab build): only plain bf16 tiles 3, 6, 10 (and 13 / 14, dispatched above)");
   if (cfg == 3) PP_LAUNCH_GEMM_V(bf16_t, 192, 192, 2, 4, 3, false, true);
   else if (cfg == 6) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
-  else if (cfg == 12) PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 2, 3, false, true, 4, true);
-  else if (cfg == 11) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, false, true, 4);
   else PP_LAUNCH_GEMM_P(bf16_t, 192, 192, 2, 4, 3, false, true, 0, true);
 #else
   if (a->dtype == PP_FP8) {
@@ -1941,7 +1858,6 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 8) PP_LAUNCH_GEMM(bf16_t, 256, 256, 2, 4, 2);
     else if (cfg == 9) PP_LAUNCH_GEMM(bf16_t, 192, 256, 2, 4, 2);
     else if (cfg == 10) PP_LAUNCH_GEMM_PP(bf16_t, 192, 192, 2, 4, 3);
-    else if (cfg == 11) { if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, true, true, 4); else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 2, 3, false, true, 4); }
     else if (gather) PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(bf16_t, 192, 192, 2, 4, 3, false, true, 4);
   } else {
@@ -1953,7 +1869,6 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     else if (cfg == 7) PP_LAUNCH_GEMM(float, 192, 384, 2, 4, 2);
     else if (cfg == 8 || cfg == 9) return fail("pp_gemm: the 256-wide tiles are built for bf16 only (fp32 fragments do not fit the register file)");
     else if (cfg == 10) PP_LAUNCH_GEMM_PP(float, 192, 192, 2, 4, 3);
-    else if (cfg == 11) return fail("pp_gemm: tile 11 (4 consumer + 4 producer waves) is built for bf16 only");
     else if (gather) PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, true, true, 4);
     else PP_LAUNCH_GEMM_W(float, 192, 192, 2, 4, 3, false, true, 4);
   }

@@ -35,6 +35,8 @@ DUAL_CHAIN_MIN_BATCH = 16
 SPLITK_AUX = True
 # bf16 heads with K <= 32 keypoints: the last deconvolution's epilogue applies the final 1x1 layer (see HeadPlan._forward)
 FUSE_FINAL = True
+# head-major q / k / v for head dims that are not whole cache lines (see VitPlan.__init__)
+HEADMAJOR_QKV = True
 
 
 def _signature(module: torch.nn.Module):
@@ -68,17 +70,22 @@ class _Workspace:
 
     def __init__(self):
         self._bufs: Dict[tuple, torch.Tensor] = {}
+        self._in_graph = set()        # keys handed out while a graph was being captured
         self._retired = []
 
     def get(self, name: str, shape, dtype, device) -> torch.Tensor:
         shape = tuple(shape)
         key = (name, shape[1:], dtype)
         t = self._bufs.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if t is None or t.shape[0] < shape[0]:
-            if t is not None:
-                self._retired.append(t)
+            if t is not None and key in self._in_graph:
+                self._retired.append(t)      # a captured graph points into it; buffers no graph has seen are freed
+                self._in_graph.discard(key)
             t = torch.empty(shape, dtype=dtype, device=device)
             self._bufs[key] = t
+        if capturing:
+            self._in_graph.add(key)
         return t[: shape[0]]
 
 
@@ -123,6 +130,10 @@ class VitPlan:
         self.nb = _dev(vit.norm.bias, device, torch.float32)
         self.neps = vit.norm.eps
         self.hidden = self.blocks[0]["fc1_w"].shape[0] if self.blocks else 4 * C
+        # bf16 models whose head rows are not whole 128-byte lines (head_dim 80: ViT-H; 32 with N > 192) and that run the
+        # streaming attention kernel: the qkv GEMM writes q / k / v head-major, so one head's rows are contiguous
+        self.headmajor = (HEADMAJOR_QKV and dtype == torch.bfloat16 and not fp8 and
+                          (self.hd == 80 or (self.hd == 32 and self.N > 192)))
         self.ws = _Workspace()
         self._chain_stream = None
 
@@ -193,8 +204,9 @@ class VitPlan:
             ops.layernorm(xres, b["n1w"], b["n1b"], b["eps1"], h)
             if i == 0 and offset_event is not None:
                 offset_event.record()      # the other chain starts here: one patch-embed GEMM + LN behind
-            ops.linear(h, b["qkv_w"], b["qkv_b"], out=qkv)
-            ops.attention(qkv, ao, B, N, self.heads, self.hd)
+            hm = (self.heads, self.hd) if self.headmajor else None
+            ops.linear(h, b["qkv_w"], b["qkv_b"], out=qkv, headmajor=hm)
+            ops.attention(qkv, ao, B, N, self.heads, self.hd, headmajor=self.headmajor)
             ops.linear(ao, b["proj_w"], b["proj_b"], out=xres, residual=xres)
             ops.layernorm(xres, b["n2w"], b["n2b"], b["eps2"], h)
             ops.linear(h, b["fc1_w"], b["fc1_b"], out=hid, epilogue=EPI_GELU)
@@ -347,11 +359,26 @@ class HeadPlan:
                                        b=_dev(bf, device, torch.float32)))
                 cin = cv.out_channels
         if isinstance(head.final_layer, nn.Identity):
-            raise NotImplementedError("final_layer_kernel_size=None is not built (never used by the reference scripts)")
-        fl = head.final_layer
-        self.final = dict(k=int(fl.kernel_size[0]), pad=int(fl.padding[0]), cin=cin,
-                          w=_dev(pack.conv_taps_major(fl.weight.detach().float().cpu()), device, dtype),
-                          b=_dev(fl.bias.detach().float(), device, torch.float32))
+            # final_layer_kernel_size=None (head.py:234-235): the last conv / deconv layer's (ReLU'd) channels ARE the maps
+            if cin != self.K:
+                raise ValueError(f"final_layer_kernel_size=None: the heatmap branch ends with {cin} channels but the "
+                                 f"head has out_channels={self.K} (Codec.decode and the aux branches expect K maps)")
+            self.final = None
+        else:
+            fl = head.final_layer
+            self.final = dict(k=int(fl.kernel_size[0]), pad=int(fl.padding[0]), cin=cin,
+                              w=_dev(pack.conv_taps_major(fl.weight.detach().float().cpu()), device, dtype),
+                              b=_dev(fl.bias.detach().float(), device, torch.float32))
+        # the implicit-GEMM layers walk their input one K-tile (128 bytes of channels) at a time inside a tap: every layer
+        # INPUT width of the heatmap branch (and the aux branches' C) must be a whole number of K-tiles
+        gran = 64 if dtype == torch.bfloat16 else 32
+        widths = [self.C] + [d["cout"] for d in self.deconvs] + [c["cout"] for c in self.convs]
+        consumed = widths[: len(self.deconvs) + len(self.convs) + (1 if self.final is not None else 0)]
+        bad = [w for w in consumed if w % gran]
+        if bad:
+            raise ValueError(f"ProbMapHead on the HIP path ({dtype}): layer input widths {bad} are not multiples of {gran} "
+                             f"channels (in_channels / deconv_out_channels / conv_out_channels feeding another layer); "
+                             "the reference's own configurations use 256-channel layers")
         # --- four aux branches: [conv3x3+BN, pool, relu] x n -> conv1x1 -> act
         prob_layers = list(head.probability_layers)
         n_stage = (len(prob_layers) - 2) // 4
@@ -391,14 +418,20 @@ class HeadPlan:
     # gather/scatter tables depend on (B, h, w) only
     def _tables_for(self, B: int, h: int, w: int) -> dict:
         key = (B, h, w)
+        capturing = torch.cuda.is_current_stream_capturing()
         t = self._tables.get(key)
         if t is not None:
             self._tables[key] = self._tables.pop(key)          # most recently used last
+            t["pinned"] = t["pinned"] or capturing
             return t
-        while len(self._tables) >= 8:                          # bounded: batch sizes vary per frame in inference
-            self._tables.pop(next(iter(self._tables)))
+        # bounded: batch sizes vary per frame in inference.  The tables are device tensors whose ADDRESSES a captured
+        # graph has baked in, so an entry that was handed out during a capture is pinned and never evicted (a replay
+        # would otherwise gather through freed memory); only eager-only entries age out.
+        evictable = [k for k, v in self._tables.items() if not v["pinned"]]
+        while len(evictable) >= 8:
+            self._tables.pop(evictable.pop(0))
         dev = self.device
-        t = dict(deconv=[], conv=[], aux=[])
+        t = dict(deconv=[], conv=[], aux=[], pinned=capturing)
         hh, ww = h, w
         for d in self.deconvs:
             ro, rm = pack.deconv_tables(B, hh, ww, d["k"], d["cin"])
@@ -409,7 +442,7 @@ class HeadPlan:
                              if c["k"] > 1 else None)
         f = self.final
         t["final"] = (pack.conv_gather_table(B, hh, ww, f["k"], f["k"], f["pad"], f["pad"], f["cin"]).to(dev)
-                      if f["k"] > 1 else None)
+                      if f is not None and f["k"] > 1 else None)
         t["hm_hw"] = (hh, ww)
         ah, aw = h, w
         for i, p in enumerate(self.pools):
@@ -465,7 +498,9 @@ class HeadPlan:
                                  bias=self.aux_b[i], rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C,
                                  strideC=C, strideBias=C)
                     else:
-                        parts = g(f"aux_part{i}", (split, M, 4 * C), torch.float32, dev)
+                        # rows leading ([split * M, 4C], partial s = rows [s * M, (s + 1) * M)): the workspace key does
+                        # not hold M, so one allocation serves every batch size up to the largest seen
+                        parts = g(f"aux_part{i}", (split * M, 4 * C), torch.float32, dev).view(split, M, 4 * C)
                         taps = 9 // split
                         ops.gemm(a, self.aux_w[i], parts, M=M, N=C, Kd=taps * C, lda=4 * C, ldw=9 * C, ldc=4 * C,
                                  rowoff=ro, seg_len=C, batch=4, strideA=C, strideW=C * 9 * C, strideC=C,
@@ -483,12 +518,12 @@ class HeadPlan:
         x, hh, ww, cin = feats, h, w, C
         f = self.final
         clamp = self.normalize is None
-        fused_final = False
+        fused_final = final_done = False
         for li, (d, (ro, rm, _, _)) in enumerate(zip(self.deconvs, tb["deconv"])):
             M = B * hh * ww
             last = li == len(self.deconvs) - 1
-            if (FUSE_FINAL and last and not self.convs and dt == torch.bfloat16 and d["cout"] == 256 and f["k"] == 1
-                    and K <= 32):
+            if (FUSE_FINAL and last and not self.convs and f is not None and dt == torch.bfloat16 and d["cout"] == 256
+                    and f["k"] == 1 and K <= 32):
                 # the last deconvolution's epilogue applies the final 1x1 layer itself: its 256-channel output
                 # (100 MB at bs 64) is never stored, and the final-layer launch is gone
                 ops.gemm(x, d["w"], heat, M=M, N=256, Kd=4 * cin, lda=cin, ldw=4 * cin, ldc=256, bias=d["b"],
@@ -498,6 +533,14 @@ class HeadPlan:
                 fused_final = True
                 hh, ww, cin = 2 * hh, 2 * ww, 256
                 break
+            if f is None and last and not self.convs:
+                # Identity final layer: this layer's ReLU'd outputs are the maps -> /T, clamp, NCHW store in its epilogue
+                ops.gemm(x, d["w"], heat, M=M, N=K, Kd=4 * cin, lda=cin, ldw=4 * cin, ldc=K, bias=d["b"], rowoff=ro,
+                         seg_len=cin, out_rowmap=rm, batch=4, strideW=K * 4 * cin, strideRowoff=4 * M, strideRowmap=M,
+                         strideBias=0, epilogue=EPI_RELU, heatmap=(K, 4 * hh * ww, self.temperature, clamp))
+                final_done = True
+                hh, ww, cin = 2 * hh, 2 * ww, K
+                break
             out = g(f"deconv{li}", (4 * M, d["cout"]), dt, dev)
             ops.gemm(x, d["w"], out, M=M, N=d["cout"], Kd=4 * cin, lda=cin, ldw=4 * cin, ldc=d["cout"],
                      bias=d["b"], rowoff=ro, seg_len=cin, out_rowmap=rm, batch=4,
@@ -505,16 +548,28 @@ class HeadPlan:
             x, hh, ww, cin = out, 2 * hh, 2 * ww, d["cout"]
         for li, (c, ro) in enumerate(zip(self.convs, tb["conv"])):
             M = B * hh * ww
-            out = g(f"conv{li}", (M, c["cout"]), dt, dev)
             kk = c["k"] * c["k"]
+            if f is None and li == len(self.convs) - 1:
+                ops.gemm(x, c["w"], heat, M=M, N=K, Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=K, bias=c["b"], rowoff=ro,
+                         seg_len=cin, epilogue=EPI_RELU, heatmap=(K, hh * ww, self.temperature, clamp))
+                final_done = True
+                break
+            out = g(f"conv{li}", (M, c["cout"]), dt, dev)
             ops.gemm(x, c["w"], out, M=M, N=c["cout"], Kd=kk * cin, lda=cin, ldw=kk * cin, ldc=c["cout"],
                      bias=c["b"], rowoff=ro, seg_len=cin, epilogue=EPI_RELU)
             x, cin = out, c["cout"]
         M = B * hh * ww
         assert heat.shape == (B, K, hh, ww)
-        kk = f["k"] * f["k"]
         es = 2 if dt == torch.bfloat16 else 4
-        if fused_final:
+        if f is None and not final_done:
+            # no deconv, no conv, no final layer: the maps are the input features themselves (degenerate but constructible)
+            nchw = torch.empty((B, K, hh, ww), dtype=torch.float32, device=dev)
+            ops.tokens_to_nchw(x, nchw, B, hh * ww, K)
+            heat.copy_(nchw / self.temperature)
+            if clamp:
+                heat.clamp_(0, 1)
+        kk = f["k"] * f["k"] if f is not None else 0
+        if fused_final or f is None:
             pass
         elif f["k"] == 1 and 64 * (cin * es + 16) + K * cin * es <= 150 * 1024:
             ops.final_heatmap(x, f["w"], f["b"], heat, B, hh * ww, cin, K, self.temperature, clamp=clamp)

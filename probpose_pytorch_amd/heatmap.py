@@ -54,6 +54,28 @@ def _device_taps(K, H, W, sigmas, device):
     return hit
 
 
+# which implementation pp_decode_f32 runs: 0 = the default per map size; _lib.DECODE_* force another one (A/B tools and
+# the equivalence tests; every form returns identical numbers)
+DECODE_FLAGS = 0
+
+# zeroed work-list buffers of the wave-per-map kernel, one per (device, stream): allocated and zeroed once, every launch
+# leaves them zeroed (include/probpose_hip.h), the address stays stable for graph replay
+_DECODE_WS: dict = {}
+
+
+def _decode_workspace(nbytes: int, dev):
+    if nbytes <= 0:
+        return None
+    key = (str(dev), int(torch.cuda.current_stream(dev).cuda_stream))
+    t = _DECODE_WS.get(key)
+    if t is None or t.numel() < nbytes:
+        if len(_DECODE_WS) > 16:
+            _DECODE_WS.clear()
+        t = torch.zeros((max(nbytes, 1 << 16),), dtype=torch.uint8, device=dev)
+        _DECODE_WS[key] = t
+    return t
+
+
 def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=None,
                      aux=None, want_conv: bool = False) -> dict:
     """Launch the fused decode on device-resident heatmaps (B,K,H,W) f32.
@@ -94,7 +116,10 @@ def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=Non
     if want_conv:
         out["conv"] = torch.empty_like(heatmaps)
     ws_bytes = L.pp_decode_workspace_bytes(B, K, H, W)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
+    if (H, W) in ((64, 48), (96, 72)):
+        ws = _decode_workspace(ws_bytes, dev)                # the self-cleaning work list: zeroed once, kept
+    else:
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     from . import ops as _ops
     with torch.cuda.device(dev):
         rc = _ops._timed("decode", float(B * K * (H * W * 4 + 16 + 28)), lambda: L.pp_decode_f32(
@@ -102,7 +127,7 @@ def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=Non
             B, K, H, W, _lib.ptr(taps), _lib.ptr(radius), den_x, den_y, in_w, in_h,
             _lib.ptr(out.get("kpts")), _lib.ptr(out["scores"]), _lib.ptr(out["locs"]),
             _lib.ptr(out.get("aux")), _lib.ptr(out.get("err")), _lib.ptr(out.get("conv")),
-            _lib.ptr(out.get("packed")), _lib.ptr(ws), _lib.stream_ptr()))
+            _lib.ptr(out.get("packed")), _lib.ptr(ws), int(DECODE_FLAGS), _lib.stream_ptr()))
     _lib.check(rc, "pp_decode_f32")
     return out
 

@@ -79,11 +79,15 @@ def pck_counts(pred, gt, mask, thr, norm_factor, return_distances: bool = False)
     thr_eff = float(np.float32(thr)) if isinstance(thr, (float, int)) and not isinstance(thr, np.generic) else float(thr)
     counts = torch.empty((2, K), dtype=torch.int32, device="cuda")
     dist = torch.empty((K, N), dtype=torch.float32, device="cuda") if return_distances else None
-    _lib.check(_lib.lib().pp_pck_counts(_lib.ptr(p), _lib.ptr(g), 0 if is_f32 else 1, _lib.ptr(m),
-                                        _lib.ptr(_as_device(nf64, torch.float64)),
-                                        _lib.ptr(_as_device(skip, torch.bool).view(torch.uint8)), thr_eff, N, K,
-                                        _lib.ptr(counts), _lib.ptr(dist), _lib.stream_ptr()), "pp_pck_counts")
+    # every operand stays referenced until the results are back: a temporary freed right after its pointer was taken
+    # goes back to the caching allocator and is handed to the next allocation before the kernel has run
+    nf_dev = _as_device(nf64, torch.float64)
+    skip_dev = _as_device(skip, torch.bool).view(torch.uint8)
+    _lib.check(_lib.lib().pp_pck_counts(_lib.ptr(p), _lib.ptr(g), 0 if is_f32 else 1, _lib.ptr(m), _lib.ptr(nf_dev),
+                                        _lib.ptr(skip_dev), thr_eff, N, K, _lib.ptr(counts), _lib.ptr(dist),
+                                        _lib.stream_ptr()), "pp_pck_counts")
     c = counts.cpu().numpy().astype(np.int64)
+    del nf_dev, skip_dev
     return (c[0], c[1], dist.cpu().numpy()) if return_distances else (c[0], c[1])
 
 

@@ -56,7 +56,7 @@ def _p(t):
 # configurations on scratch outputs (HIP events, outside any graph capture) and caches the winner.
 AUTOTUNE = False
 _TUNE_CACHE: dict = {}
-_TUNE_CANDIDATES = (2, 3, 4, 5, 6, 7, 9, 10, 14)
+_TUNE_CANDIDATES = (2, 3, 4, 5, 6, 7, 9, 10, 13, 14)
 
 
 def save_tune_cache(path: str) -> None:
@@ -118,7 +118,7 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
          rowbias_period=0, rowoff=None, seg_len=0, out_rowmap=None, batch=1, strideA=0, strideW=0,
          strideC=0, strideBias=0, strideRowoff=0, strideRowmap=0, epilogue=0, heatmap=None, tile=0,
          colscale=None, out_scale=None, splitk=1, strideA_k=0, strideW_k=0,
-         strideC_k=0, strideRowoff_k=0, fuse_final=None):
+         strideC_k=0, strideRowoff_k=0, fuse_final=None, headmajor=None):
     """C = epilogue(A @ W^T) on MFMA; see pp_gemm in include/probpose_hip.h.
     fp8 (A, W torch.float8_e4m3fn): ``colscale`` [N] f32 = activation scale x weight-row scale; ``out`` may be
     bf16, f32 (with residual) or fp8 (then ``out_scale`` = the scale of the output tensor)."""
@@ -149,6 +149,9 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
         a.final_w, a.final_b = _p(fw), _p(fb)
         a.hm_K, a.hm_HW, a.hm_temperature = fk, fhw, ftemp
         tile = 9
+    if headmajor is not None:     # (heads, head_dim): out is written [3][heads][M][head_dim] (the qkv projection)
+        epilogue |= _lib.EPI_HEADMAJOR
+        a.hm_K, a.hm_HW = headmajor
     if a.dtype == PP_FP8:
         if colscale is None or A.dtype != FP8:
             raise TypeError("fp8 GEMM: A and W must both be float8_e4m3fn and colscale [N] f32 is required")
@@ -175,7 +178,7 @@ def gemm(A, W, out, *, M, N, Kd, lda, ldw, ldc, bias=None, residual=None, rowbia
 
 
 def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=None, tile=0, colscale=None,
-           out_scale=None):
+           out_scale=None, headmajor=None):
     """x [M,K] @ w[N,K]^T (+bias, activation / fp32 residual add)."""
     M, Kd = x.shape
     N = w.shape[0]
@@ -185,7 +188,8 @@ def linear(x, w, bias=None, *, out=None, epilogue=0, residual=None, out_dtype=No
         dt = torch.float32 if (epilogue & EPI_OUT_F32) else (out_dtype or (torch.bfloat16 if w.dtype == FP8 else w.dtype))
         out = torch.empty((M, N), dtype=dt, device=x.device)
     return gemm(x, w, out, M=M, N=N, Kd=Kd, lda=x.stride(0), ldw=w.stride(0), ldc=out.stride(0),
-                bias=bias, residual=residual, epilogue=epilogue, tile=tile, colscale=colscale, out_scale=out_scale)
+                bias=bias, residual=residual, epilogue=epilogue, tile=tile, colscale=colscale, out_scale=out_scale,
+                headmajor=headmajor)
 
 
 def quantize_rows_fp8(w: torch.Tensor):
@@ -211,7 +215,12 @@ def layernorm(x, gamma, beta, eps, out, out_scale=None):
     return out
 
 
-def attention(qkv, out, B, N, heads, hd, out_scale=None):
+def attention(qkv, out, B, N, heads, hd, out_scale=None, headmajor=False):
+    if headmajor:            # qkv [3][heads][B*N][hd] as linear(..., headmajor=(heads, hd)) wrote it
+        rc = _timed("attention", 4.0 * B * heads * N * N * hd,
+                    lambda: _lib.lib().pp_attention_headmajor(_p(qkv), _p(out), B, N, heads, hd, _lib.stream_ptr()))
+        _lib.check(rc, "pp_attention_headmajor")
+        return out
     if out.dtype == FP8:     # e4m3 output with a static per-tensor scale (fp8 mode)
         rc = _timed("attention", 4.0 * B * heads * N * N * hd,
                     lambda: _lib.lib().pp_attention_fp8out(_p(qkv), _p(out), B, N, heads, hd, 1.0 / float(out_scale),

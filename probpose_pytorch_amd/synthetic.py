@@ -35,9 +35,10 @@ def _bn(g, sd, prefix, C):
 
 
 def synthetic_head_state(C: int, K: int, n_pools: int = 3, deconv_out=(256, 256), seed: int = 0,
-                         final_kernel: int = 1) -> "OrderedDict[str, torch.Tensor]":
-    """state_dict of ``ProbMapHead(C, K, pools, deconv_out, (4,)*n, final_layer_kernel_size=1)``
-    (parameter names of reference head.py: deconv_layers / final_layer / *_layers)."""
+                         final_kernel=1, conv_out=(), conv_kernels=()) -> "OrderedDict[str, torch.Tensor]":
+    """state_dict of ``ProbMapHead(C, K, pools, deconv_out, (4,)*n, conv_out, conv_kernels,
+    final_layer_kernel_size=final_kernel)`` (parameter names of reference head.py: deconv_layers / conv_layers /
+    final_layer / *_layers; ``final_kernel=None``: nn.Identity, no final parameters)."""
     g = _gen(seed)
     sd = OrderedDict()
     cin = C
@@ -46,9 +47,15 @@ def synthetic_head_state(C: int, K: int, n_pools: int = 3, deconv_out=(256, 256)
         sd[f"deconv_layers.{3 * i}.weight"] = _normal(g, (cin, cout, 4, 4), math.sqrt(2.0 / (cin * 4)))
         _bn(g, sd, f"deconv_layers.{3 * i + 1}.", cout)
         cin = cout
-    sd["final_layer.weight"] = _normal(g, (K, cin, final_kernel, final_kernel),
-                                       math.sqrt(1.0 / (cin * final_kernel ** 2)))
-    sd["final_layer.bias"] = _normal(g, (K,), 0.1)
+    for i, (cout, k) in enumerate(zip(conv_out, conv_kernels)):
+        sd[f"conv_layers.{3 * i}.weight"] = _normal(g, (cout, cin, k, k), math.sqrt(2.0 / (cin * k * k)))
+        sd[f"conv_layers.{3 * i}.bias"] = _normal(g, (cout,), 0.1)
+        _bn(g, sd, f"conv_layers.{3 * i + 1}.", cout)
+        cin = cout
+    if final_kernel is not None:
+        sd["final_layer.weight"] = _normal(g, (K, cin, final_kernel, final_kernel),
+                                           math.sqrt(1.0 / (cin * final_kernel ** 2)))
+        sd["final_layer.bias"] = _normal(g, (K,), 0.1)
     for name in ("probability", "visibility", "oks", "error"):
         for i in range(n_pools):
             sd[f"{name}_layers.{4 * i}.weight"] = _normal(g, (C, C, 3, 3), math.sqrt(2.0 / (C * 9)))

@@ -35,10 +35,10 @@ def test_argument_validation_without_gpu(built_lib):
     """Host-side checks run before any launch, so they can be exercised on CPU."""
     from probpose_pytorch_amd import _lib
     rc = built_lib.pp_decode_f32(None, None, None, None, None, 1, 17, 64, 48, None, None,
-                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, None)
+                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, 0, None)
     assert rc != 0 and b"null" in built_lib.pp_last_error()
-    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == (17 + 1) * 4     # hand-over list of the wave-per-map path
-    assert built_lib.pp_decode_workspace_bytes(2, 133, 96, 72) == (2 * 133 + 1) * 4
+    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == (17 + 4) * 4     # work list of the wave-per-map path
+    assert built_lib.pp_decode_workspace_bytes(2, 133, 96, 72) == (2 * 133 + 4) * 4
     assert built_lib.pp_decode_workspace_bytes(1, 17, 32, 24) == 0                # fits LDS, no list
     assert built_lib.pp_decode_workspace_bytes(1, 20, 256, 256) == 20 * 256 * 256 * 12
     with pytest.raises(_lib.HipExtensionError):
@@ -56,3 +56,27 @@ def test_product_path_fails_loudly_without_gpu():
         get_heatmap_expected_value(hm, np.full(17, 0.05))
     with pytest.raises(_lib.HipExtensionError):
         Codec(ProbMap((192, 256), (48, 64), np.full(17, 0.05))).decode_heatmap(hm)
+
+
+def test_gemm_argument_validation_without_gpu(built_lib):
+    """pp_gemm's host-side refusals come before any launch (no GPU needed): retired tile selectors, the fused final
+    layer on a C pointer that cannot take the LDS epilogue (it would otherwise fall through to the direct store loop
+    and write 256-channel rows into the [B,K,HW] heat buffer), persistent tile on a residual layer, decode flags."""
+    import ctypes as C
+    from probpose_pytorch_amd import _lib
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C = 0x1000, 0x2000, 0x3000
+    a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc, a.batch, a.dtype = 192, 256, 256, 256, 256, 256, 1, _lib.PP_BF16
+    for tile in (11, 12, 15, -1):
+        a.tile = tile
+        assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tile" in built_lib.pp_last_error()
+    a.tile, a.epilogue = 9, _lib.EPI_FUSE_FINAL | _lib.EPI_RELU
+    a.final_w, a.final_b, a.hm_K, a.hm_HW, a.hm_temperature = 0x4000, 0x5000, 17, 3072, 0.5
+    a.C = 0x3004                                           # 4-byte aligned only: no LDS epilogue possible
+    assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"FUSE_FINAL" in built_lib.pp_last_error()
+    a.C, a.epilogue, a.tile = 0x3000, _lib.EPI_RESIDUAL | _lib.EPI_OUT_F32, 13
+    a.residual = 0x3000
+    assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tile 13" in built_lib.pp_last_error()
+    rc = built_lib.pp_decode_f32(0x1000, None, None, None, None, 1, 17, 64, 48, 0x2000, 0x3000,
+                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, 64, None)
+    assert rc != 0 and b"flags" in built_lib.pp_last_error()

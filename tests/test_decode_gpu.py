@@ -209,10 +209,10 @@ def test_decode_c_entry_without_workspace_takes_the_workgroup_kernels(pp):
         kpts = torch.zeros((B, K, 2), dtype=torch.float64, device="cuda")
         scores = torch.zeros((B, K), device="cuda")
         locs = torch.zeros((B, K, 2), device="cuda")
-        ws = torch.empty((int(L.pp_decode_workspace_bytes(B, K, H, W)),), dtype=torch.uint8, device="cuda")
+        ws = torch.zeros((int(L.pp_decode_workspace_bytes(B, K, H, W)),), dtype=torch.uint8, device="cuda")
         rc = L.pp_decode_f32(_lib.ptr(hm), None, None, None, None, B, K, H, W, _lib.ptr(taps), _lib.ptr(radius),
                              float(W - 1), float(H - 1), 192.0, 256.0, _lib.ptr(kpts), _lib.ptr(scores), _lib.ptr(locs),
-                             None, None, None, None, _lib.ptr(ws) if with_ws else None, _lib.stream_ptr())
+                             None, None, None, None, _lib.ptr(ws) if with_ws else None, 0, _lib.stream_ptr())
         _lib.check(rc, "pp_decode_f32")
         res.append((kpts.cpu().numpy(), scores.cpu().numpy(), locs.cpu().numpy()))
     for a, b in zip(*res):
@@ -238,12 +238,15 @@ def test_full_size_wave_decode_equals_all_pixel_decode(pp, monkeypatch):
         hm = torch.where(n % 11 == 5, torch.zeros_like(hm), hm).contiguous()
         sig = orc.COCO17_SIGMAS if K == 17 else np.random.default_rng(133).uniform(0.02, 0.11, K)
         probmap = pp.ProbMap(insz, (W, H), sig)
-        for v in ("PP_DECODE_EXACT_ALL", "PP_DECODE_SCREEN", "PP_DECODE_WAVE"):
-            monkeypatch.delenv(v, raising=False)
+        from probpose_pytorch_amd import _lib, heatmap as hmod
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", 0)
         fast = {k: v.cpu().numpy() for k, v in probmap.decode_device(hm).items()}
-        monkeypatch.setenv("PP_DECODE_EXACT_ALL", "1")
+        again = {k: v.cpu().numpy() for k, v in probmap.decode_device(hm).items()}     # the work list cleaned itself up
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_ALL_PIXEL)
         slow = {k: v.cpu().numpy() for k, v in probmap.decode_device(hm).items()}
-        monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", 0)
+        for k in ("kpts", "scores", "locs"):
+            np.testing.assert_array_equal(again[k], slow[k], err_msg=f"second launch {k} {hm.shape}")
         for k in ("kpts", "scores", "locs"):
             np.testing.assert_array_equal(fast[k], slow[k], err_msg=f"{k} {hm.shape}")
         assert np.isfinite(fast["kpts"]).all()
@@ -287,8 +290,8 @@ def test_encode_batched_equals_per_crop_oracle(pp):
 
 def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
     """The default decode evaluates the float64 convolution only at the float32-screened candidates: one wave per map
-    (decode_wave_kernel) on 64x48 and 96x72 maps, one workgroup per map (decode_screen_kernel; PP_DECODE_WAVE=0 +
-    PP_DECODE_SCREEN=1 force it everywhere) otherwise; PP_DECODE_EXACT_ALL=1 selects the all-pixel float64 kernel.
+    (decode_wave_kernel) on 64x48 and 96x72 maps, one workgroup per map (decode_screen_kernel; flags PP_DECODE_NO_WAVE |
+    PP_DECODE_SCREEN force it everywhere) otherwise; PP_DECODE_ALL_PIXEL selects the all-pixel float64 kernel.
     All three must return identical numbers on random, peaked, flat, saturated, tied, negative, non-finite and tiny
     maps."""
     import torch
@@ -327,17 +330,14 @@ def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
         codec = pp.Codec(pp.ProbMap((4 * W, 4 * H), (W, H), sig))
         aux = [rng.random((B, K, 1, 1), dtype=np.float32) for _ in range(4)]
         pred = tuple(torch.from_numpy(a).cuda() for a in (hm, *aux))
-        for v in ("PP_DECODE_EXACT_ALL", "PP_DECODE_SCREEN", "PP_DECODE_WAVE"):
-            monkeypatch.delenv(v, raising=False)
+        from probpose_pytorch_amd import _lib, heatmap as hmod
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", 0)
         legs = {"default": codec.decode(pred)}
-        monkeypatch.setenv("PP_DECODE_WAVE", "0")
-        monkeypatch.setenv("PP_DECODE_SCREEN", "1")          # the workgroup-per-map screened form on every map size
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN)   # workgroup-per-map screened form
         legs["screened"] = codec.decode(pred)
-        monkeypatch.delenv("PP_DECODE_SCREEN", raising=False)
-        monkeypatch.delenv("PP_DECODE_WAVE", raising=False)
-        monkeypatch.setenv("PP_DECODE_EXACT_ALL", "1")
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_ALL_PIXEL)
         slow = codec.decode(pred)
-        monkeypatch.delenv("PP_DECODE_EXACT_ALL", raising=False)
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", 0)
         for name, fast in legs.items():
             np.testing.assert_array_equal(fast[0][0], slow[0][0], err_msg=f"{name} {hm.shape}")
             np.testing.assert_array_equal(fast[0][1], slow[0][1], err_msg=f"{name} {hm.shape}")

@@ -51,7 +51,10 @@ def test_gemm_plain_bias_tails(ops, dtype, tile, M, N, K):
 
 @pytest.mark.parametrize("tile", [13, 14])
 @pytest.mark.parametrize("M,N,K,epi", [(384, 768, 768, "gelu"), (1536, 2304, 768, "none"), (200, 264, 128, "relu"),
-                                       (2000, 388, 1024, "resid")])
+                                       (2000, 388, 1024, "resid"),
+                                       # more tiles than CUs: the persistent form walks 2 - 3 tiles per workgroup (XCD-blocked
+                                       # order / plain order), ragged edges, a one-K-tile stream
+                                       (12288, 2304, 768, "gelu"), (3000, 4000, 128, "none"), (5000, 3080, 64, "relu")])
 def test_gemm_experimental_forms_tile13_tile14(ops, tile, M, N, K, epi):
     """The persistent stream (13) and the two-workgroups-per-CU form (14): bf16 plain layers, checked like any tile."""
     dtype = torch.bfloat16
@@ -235,6 +238,32 @@ def test_attention(ops, dtype, B, N, heads, hd):
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * N, C)
     tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=2 ** -6, atol=2e-2)
     torch.testing.assert_close(out.double(), ref, **tol)
+
+
+@pytest.mark.parametrize("tile", [0, 2, 3, 6, 7, 10, 13])
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 432, 16, 80), (3, 192, 12, 32), (1, 50, 4, 64), (2, 433, 2, 80)])
+def test_headmajor_qkv_projection_and_attention(ops, tile, B, N, heads, hd):
+    """The qkv projection written head-major ([3][heads][B*N][hd], PP_EPI_HEADMAJOR) by every tile form that takes the
+    flag, then the streaming attention kernel reading that layout: (a) the head-major buffer holds exactly the
+    row-major projection's numbers, (b) attention on it == attention of torch on the same q / k / v."""
+    C, M = heads * hd, B * N
+    x = _rand((M, C), torch.bfloat16, 1)
+    W = _rand((3 * C, C), torch.bfloat16, 2, C ** -0.5)
+    b = _rand((3 * C,), torch.float32, 3)
+    rowmajor = ops.linear(x, W, b, tile=tile)
+    hmaj = torch.full((M, 3 * C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.linear(x, W, b, out=hmaj, tile=tile, headmajor=(heads, hd))
+    want = rowmajor.reshape(M, 3, heads, hd).permute(1, 2, 0, 3).contiguous()        # [3][heads][M][hd]
+    assert torch.equal(hmaj.reshape(3, heads, M, hd), want)
+    out = torch.empty((M, C), dtype=torch.bfloat16, device="cuda")
+    ops.attention(hmaj, out, B, N, heads, hd, headmajor=True)
+    q, k, v = want.double().reshape(3, heads, B, N, hd).permute(0, 2, 1, 3, 4).unbind(0)   # (B, heads, N, hd)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(M, C)
+    torch.testing.assert_close(out.double(), ref, rtol=2 ** -6, atol=2e-2)
+    # and the same numbers as the row-major path of the same kernel family
+    out_rm = torch.empty_like(out)
+    ops.attention(rowmajor, out_rm, B, N, heads, hd)
+    torch.testing.assert_close(out.float(), out_rm.float(), rtol=2 ** -6, atol=2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

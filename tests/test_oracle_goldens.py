@@ -156,3 +156,75 @@ def test_encode_restatement_equals_reference_golden(name, K, in_size, hm_size, s
     assert np.array_equal(e["heatmaps"][:n], g["heatmaps"])
     assert np.array_equal(e["keypoint_weights"], g["weights"]) and np.array_equal(e["in_image"], g["in_image"])
     assert np.array_equal(e["heatmap_keypoints"], g["heatmap_keypoints"])
+
+
+HEAD_VARIANTS = {
+    # name: (C, K, pools, feature hw, deconv_out, conv_out, conv_kernels, final_kernel, seed) -- as minted by
+    # tests/golden/make_goldens_head_variants.py from the imported reference head
+    "A": (128, 17, [(4, 3), (2, 2), (2, 2)], (16, 12), (64, 64), (64,), (3,), 3, 21),
+    "B": (128, 17, [(4, 3), (2, 2), (2, 2)], (16, 12), (64,), (64, 17), (3, 1), None, 22),
+    "C": (64, 5, [(4, 3), (2, 2)], (8, 6), (), (64,), (1,), 1, 23),
+}
+
+
+@pytest.mark.parametrize("name", sorted(HEAD_VARIANTS))
+def test_head_restatement_variants_match_reference_golden(name):
+    """The constructor branches beside the default head: conv stack (head.py:407-431), final kernel 3, Identity final
+    layer (head.py:234-235), no deconvolution -- oracle vs the reference ProbMapHead's own outputs."""
+    import torch
+    from probpose_pytorch_amd.synthetic import synthetic_features, synthetic_head_state
+    C, K, pools, (h, w), dec, conv, ck, fk, seed = HEAD_VARIANTS[name]
+    g = np.load(os.path.join(GOLDEN, "head_variants.npz"))
+    sd = synthetic_head_state(C, K, n_pools=len(pools), deconv_out=dec, seed=seed, final_kernel=fk, conv_out=conv,
+                              conv_kernels=ck)
+    feats = synthetic_features(2, C, h, w, seed=seed + 100)
+    with torch.no_grad():
+        out = orc.head_forward(sd, feats, pools=pools, n_deconv=len(dec), final_kernel=fk, conv_kernels=ck)
+    for o, key in zip(out, ("heatmaps", "prob", "vis", "oks", "err")):
+        np.testing.assert_allclose(o.numpy(), g[f"{name}_{key}"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,depth,heads,img", [(96, 2, 4, (64, 48)), (384, 3, 12, (64, 48)), (128, 2, 2, (96, 64))])
+def test_vit_restatement_against_torch_transformer_encoder(C, depth, heads, img):
+    """Backbone parity cannot be pinned on the reference (its ViT is timm's, not importable, and the reference holds no
+    fixture for it).  The next best thing is an INDEPENDENT implementation of the same architecture from a library that
+    is present: torch.nn.TransformerEncoderLayer(norm_first=True, activation='gelu', layer_norm_eps=1e-6) is the same
+    pre-LN block (x += MHA(LN1 x); x += fc2(GELU(fc1(LN2 x)))) with the same [3][heads][head_dim] in-projection layout
+    as timm's fused qkv Linear (backbone.py:26-33 builds it with timm defaults: qkv_bias, exact-erf GELU, no
+    LayerScale).  Weights copied from the timm-named state_dict; patch embedding = Conv2d(3, C, 16, stride 16), learned
+    position table added, final LayerNorm: outputs agree with oracle.vit_forward_features to 3e-5."""
+    import torch
+    from torch import nn
+    from probpose_pytorch_amd.synthetic import synthetic_vit_state
+    sd = synthetic_vit_state(img_size=img, patch=16, embed_dim=C, depth=depth, seed=7)
+    x = torch.rand(2, 3, *img, generator=torch.Generator().manual_seed(8))
+    layers = []
+    for i in range(depth):
+        lyr = nn.TransformerEncoderLayer(d_model=C, nhead=heads, dim_feedforward=4 * C, dropout=0.0, activation="gelu",
+                                         layer_norm_eps=1e-6, batch_first=True, norm_first=True)
+        p = f"blocks.{i}."
+        with torch.no_grad():
+            lyr.self_attn.in_proj_weight.copy_(sd[p + "attn.qkv.weight"])
+            lyr.self_attn.in_proj_bias.copy_(sd[p + "attn.qkv.bias"])
+            lyr.self_attn.out_proj.weight.copy_(sd[p + "attn.proj.weight"])
+            lyr.self_attn.out_proj.bias.copy_(sd[p + "attn.proj.bias"])
+            lyr.norm1.weight.copy_(sd[p + "norm1.weight"]); lyr.norm1.bias.copy_(sd[p + "norm1.bias"])
+            lyr.norm2.weight.copy_(sd[p + "norm2.weight"]); lyr.norm2.bias.copy_(sd[p + "norm2.bias"])
+            lyr.linear1.weight.copy_(sd[p + "mlp.fc1.weight"]); lyr.linear1.bias.copy_(sd[p + "mlp.fc1.bias"])
+            lyr.linear2.weight.copy_(sd[p + "mlp.fc2.weight"]); lyr.linear2.bias.copy_(sd[p + "mlp.fc2.bias"])
+        layers.append(lyr)
+    pe = nn.Conv2d(3, C, 16, stride=16)
+    norm = nn.LayerNorm(C, eps=1e-6)
+    with torch.no_grad():
+        pe.weight.copy_(sd["patch_embed.proj.weight"]); pe.bias.copy_(sd["patch_embed.proj.bias"])
+        norm.weight.copy_(sd["norm.weight"]); norm.bias.copy_(sd["norm.bias"])
+    for train_mode in (False, True):           # eval takes torch's fused fast path, train mode (dropout 0) the plain one
+        with torch.no_grad():
+            t = pe(x).flatten(2).transpose(1, 2) + sd["pos_embed"]
+            for lyr in layers:
+                lyr.train(train_mode)
+                t = lyr(t)
+            want = norm(t)
+            got = orc.vit_forward_features(sd, x, patch=16, heads=heads)
+        assert got.shape == want.shape == (2, (img[0] // 16) * (img[1] // 16), C)
+        torch.testing.assert_close(got, want, rtol=0, atol=3e-5)

@@ -72,3 +72,38 @@ def test_all_gather_decoded_gloo_world2(total):
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), res
     assert all(r[2] == (total, 17, 7) for r in res)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher around it (the way the driver runs --gpus 1) must measure N GPUs:
+    the parent assembles the torch.distributed.run command (rendezvous on 127.0.0.1), runs it as a CHILD (never an exec),
+    passes its own arguments through and returns the children's status; under a launcher (WORLD_SIZE set) it does not."""
+    import subprocess
+    import sys
+
+    import bench
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "7", "--warmup", "2"], 4, 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(bench.__file__ if bench.__file__ in cmd else next(c for c in cmd if c.endswith("bench.py")))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    calls = []
+
+    def fake_call(argv, **kw):
+        calls.append((argv, kw))
+        return 0 if len(calls) == 1 else 3          # build ok, ranks exit 3
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench.launch_ranks(["--gpus", "2"], 2) == 3
+    assert len(calls) == 2 and "g.build()" in calls[0][0][-1]          # the build runs in a child, before the ranks
+    assert "--nproc-per-node=2" in calls[1][0] and calls[1][1]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # main(): --gpus 2 with no WORLD_SIZE goes through launch_ranks and exits with its status ...
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "1"])
+    monkeypatch.setattr(bench, "launch_ranks", lambda argv, n: 17 if (argv, n) == (["--gpus", "2", "--steps", "1"], 2) else 1)
+    try:
+        bench.main()
+        raise AssertionError("main() should have exited")
+    except SystemExit as e:
+        assert e.code == 17

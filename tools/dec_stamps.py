@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = C.CDLL(os.path.join(ROOT, "probpose_pytorch_amd", "lib", "diag", "libpp_dec_stamps.so"))
 L.pp_decode_f32.restype = C.c_int
 vp, i, d = C.c_void_p, C.c_int, C.c_double
-L.pp_decode_f32.argtypes = [vp] * 5 + [i] * 4 + [vp, vp] + [d] * 4 + [vp] * 9
+L.pp_decode_f32.argtypes = [vp] * 5 + [i] * 4 + [vp, vp] + [d] * 4 + [vp] * 8 + [i, vp]
 B, K, H, W = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 17, 64, 48
 sig = np.array([.026, .025, .025, .035, .035, .079, .079, .072, .072, .062, .062, .107, .107, .087, .087, .089, .089])
 taps, radius = oks_tap_table(K, H, W, sig)
@@ -26,7 +26,7 @@ scores = torch.zeros((B, K), device="cuda")
 for _ in range(3):
     rc = L.pp_decode_f32(hm.data_ptr(), None, None, None, None, B, K, H, W, taps.data_ptr(), radius.data_ptr(),
                          47.0, 63.0, 192.0, 256.0, kpts.data_ptr(), scores.data_ptr(), locs.data_ptr(), None, None,
-                         None, None, None, torch.cuda.current_stream().cuda_stream)
+                         None, None, None, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
 torch.cuda.synchronize()
 st = locs[2 * B * K: 2 * B * K + B * K * 16].view(torch.int64).cpu().numpy().reshape(B * K, 8)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B the screened decode (default) against the all-pixel float64 decode (PP_DECODE_EXACT_ALL=1) in ONE process:
+"""A/B the decode forms (pp_decode_f32 flags: default wave-per-map / workgroup-per-map screened / all-pixel float64) in ONE process:
 HIP-event time of the bare C call on resident buffers, interleaved rounds, median."""
 import ctypes as C
 import os
@@ -27,21 +27,20 @@ for (B, K, H, W, sig) in ((64, 17, 64, 48, orc.COCO17_SIGMAS), (256, 17, 64, 48,
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.pp_decode_workspace_bytes.restype = C.c_size_t
     nws = L.pp_decode_workspace_bytes(B, K, H, W)
-    ws = torch.empty((max(nws, 4),), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros((max(nws, 16),), dtype=torch.uint8, device="cuda")
+    MODES = {"default": 0, "wg screened": _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN, "all-pixel f64": _lib.DECODE_ALL_PIXEL}
 
-    def call():
+    def call(flags=0):
         rc = L.pp_decode_f32(hm.data_ptr(), None, None, None, None, B, K, H, W, taps.data_ptr(), radius.data_ptr(),
                              float(W - 1), float(H - 1), float(4 * W), float(4 * H), kpts.data_ptr(), scores.data_ptr(),
-                             locs.data_ptr(), None, None, None, None, ws.data_ptr() if nws else None, st)
+                             locs.data_ptr(), None, None, None, None, ws.data_ptr() if nws else None, flags, st)
         assert rc == 0, L.pp_last_error()
 
-    res = {}
-    for mode in ("screened", "all-pixel f64"):
-        res[mode] = []
+    res = {m: [] for m in MODES}
     for rnd in range(5):
-        for mode in ("screened", "all-pixel f64"):
-            os.environ["PP_DECODE_EXACT_ALL"] = "1" if mode != "screened" else "0"
-            os.environ["PP_DECODE_SCREEN"] = "1" if mode == "screened" else "0"
+        for mode, fl in MODES.items():
+            call_ = call
+            call = lambda fl=fl: call_(fl)
             for _ in range(3):
                 call()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,8 +50,8 @@ for (B, K, H, W, sig) in ((64, 17, 64, 48, orc.COCO17_SIGMAS), (256, 17, 64, 48,
             e.record()
             e.synchronize()
             res[mode].append(s.elapsed_time(e) / 20 * 1e3)
+            call = call_
     byts = B * K * H * W * 4
     for mode, t in res.items():
         m = float(np.median(t))
         print(f"B={B:5d} K={K:3d} {H}x{W}  {mode:14s} {m:8.1f} us  {byts / m / 1e3:8.1f} GB/s  ({byts / m / 1e3 / 8000:.3f} of 8 TB/s)")
-os.environ["PP_DECODE_EXACT_ALL"] = "0"

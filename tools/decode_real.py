@@ -32,8 +32,14 @@ def t(fn, n=20):
     return s.elapsed_time(e) / n * 1e3
 
 
-for env in ({}, {"PP_DECODE_WAVE": "0"}, {"PP_DECODE_EXACT_ALL": "1"}):
-    for k in ("PP_DECODE_WAVE", "PP_DECODE_EXACT_ALL"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    print(f"{str(env):32s} model heatmaps {tuple(hm.shape)}: {t(lambda: codec.probmap.decode_device(hm)):8.1f} us", flush=True)
+from probpose_pytorch_amd import _lib, heatmap as hmod
+
+res = {}
+for rnd in range(5):                 # interleaved rounds, medians
+    for name, flags in (("default (wave-per-map, one launch)", 0), ("workgroup-per-map screened", _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN),
+                        ("all-pixel float64", _lib.DECODE_ALL_PIXEL)):
+        hmod.DECODE_FLAGS = flags
+        res.setdefault(name, []).append(t(lambda: codec.probmap.decode_device(hm)))
+hmod.DECODE_FLAGS = 0
+for name, v in res.items():
+    print(f"{name:38s} model heatmaps {tuple(hm.shape)}: {sorted(v)[len(v) // 2]:8.1f} us (Python call + launch included)", flush=True)

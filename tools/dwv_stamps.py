@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 L = C.CDLL(os.path.join(ROOT, "probpose_pytorch_amd", "lib", "diag", "libpp_dwv_stamps.so"))
 L.pp_decode_f32.restype = C.c_int
 vp, i, d = C.c_void_p, C.c_int, C.c_double
-L.pp_decode_f32.argtypes = [vp] * 5 + [i] * 4 + [vp, vp] + [d] * 4 + [vp] * 9
+L.pp_decode_f32.argtypes = [vp] * 5 + [i] * 4 + [vp, vp] + [d] * 4 + [vp] * 8 + [i, vp]
 cfg = bench.CONFIGS["vit_b"]
 dev = torch.device("cuda", 0)
 model, codec, sd = bench.build(cfg, torch.bfloat16, dev)
@@ -30,11 +30,11 @@ locs = torch.zeros((B * K * 2 + B * K * 16 + 64,), dtype=torch.float32, device="
 kpts = torch.zeros((B, K, 2), dtype=torch.float64, device="cuda")
 scores = torch.zeros((B, K), device="cuda")
 L.pp_decode_workspace_bytes.restype = C.c_size_t
-ws = torch.empty((L.pp_decode_workspace_bytes(B, K, H, W),), dtype=torch.uint8, device="cuda")
+ws = torch.zeros((L.pp_decode_workspace_bytes(B, K, H, W),), dtype=torch.uint8, device="cuda")
 for _ in range(3):
     rc = L.pp_decode_f32(hm.data_ptr(), None, None, None, None, B, K, H, W, taps.data_ptr(), radius.data_ptr(),
                          47.0, 63.0, 192.0, 256.0, kpts.data_ptr(), scores.data_ptr(), locs.data_ptr(), None, None,
-                         None, None, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                         None, None, ws.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
 torch.cuda.synchronize()
 st = locs[2 * B * K: 2 * B * K + B * K * 16].view(torch.int64).cpu().numpy().reshape(B * K, 8)
