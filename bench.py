@@ -490,12 +490,13 @@ def main():
                        "gflop_per_crop": round(flops_per_crop(cfg) / 1e9, 2)},
             "decode_ms": round(d_t * 1e3, 4),
             "model_tflops": round(flops_per_crop(cfg) * crops_per_s / world / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (tile forms 2-10) / pp::gemm_duo_kernel (14), whichever the tuner picked per shape", "achieved": round(achieved, 2), "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (tile forms 2-10) / pp::gemm_persist_kernel (13) / pp::gemm_duo_kernel (14), whichever the tuner picked per shape", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": g_traffic,
                          "traffic_source": traffic_src, "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
                          "flop_per_launch": round(g_flops / max(g_n, 1), 0)},
-            "roofline_decode": {"bound": "hbm", "kernel": "pp::decode_wave_kernel" if (H // 4, W // 4) in ((64, 48), (96, 72))
-                                else "pp::decode_lds_kernel / pp::decode_screen_kernel",
+            "roofline_decode": {"bound": "hbm", "kernel": ("pp::decode_wave_kernel" if B * cfg["K"] > 2 * 256 * (3 if H // 4 == 64 else 1)
+                                                           else "pp::decode_lds_kernel (batches up to two rounds of its workgroups)")
+                                if (H // 4, W // 4) in ((64, 48), (96, 72)) else "pp::decode_lds_kernel / pp::decode_screen_kernel",
                                 "achieved": round(d_bytes / d_t / 1e9, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                 "frac": round(d_bytes / d_t / 1e9 / PEAK_HBM_GBPS, 4), "traffic": d_traffic,
                                 "bytes_per_launch": d_bytes},

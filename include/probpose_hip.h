@@ -89,12 +89,17 @@ int pp_device_ok(void);
  * fast path; NULL selects the workgroup-per-map kernels instead) which the caller ZEROES ONCE when it allocates it (every
  * launch returns it to zero itself) and must not share between launches that may run concurrently; 0 for other maps that
  * fit in LDS; a float64 + float32 image of the batch for maps that do not.
- * flags: 0 = the default form per map size; PP_DECODE_NO_WAVE / PP_DECODE_SCREEN / PP_DECODE_ALL_PIXEL select the
+ * flags: 0 = the default form per map size and batch size (64x48 / 96x72: the all-pixel kernel up to ~1 536 / ~512
+ * maps, the wave-per-map kernel above); PP_DECODE_NO_WAVE / PP_DECODE_SCREEN / PP_DECODE_ALL_PIXEL select the
  * other implementations (A/B measurements and the equivalence tests: all forms return identical numbers).
  * ---------------------------------------------------------------------- */
 #define PP_DECODE_NO_WAVE 1             /* not the wave-per-map kernel (64x48 / 96x72 maps)                  */
 #define PP_DECODE_SCREEN 2              /* the workgroup-per-map screened kernel on every map that fits LDS  */
 #define PP_DECODE_ALL_PIXEL 4           /* float64 convolution of every pixel (the round-1 kernel)          */
+#define PP_DECODE_WAVE 16               /* the wave-per-map kernel at any batch size (default: above two rounds of the
+                                           all-pixel kernel's resident workgroups, ~1 536 maps of 64x48)      */
+#define PP_DECODE_NO_HELPERS 8          /* wave-per-map kernel without helper workgroups (the last screening workgroup
+                                           decodes every listed map: measurements only)                       */
 size_t pp_decode_workspace_bytes(int B, int K, int H, int W);
 int pp_decode_f32(const float *heatmaps, const float *prob, const float *vis,
                   const float *oks, const float *err, int B, int K, int H, int W,

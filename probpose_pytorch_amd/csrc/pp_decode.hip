@@ -737,8 +737,8 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 // pushes the map onto a work list in the workspace and WHOLE WORKGROUPS of the same launch decode those maps with the
 // all-pixel float64 algorithm (decode_lds_map) -- one launch, no count-reset kernel, no follow-up kernel (round 2 ran
 // three launches: 5 + 21 + 14 us at bs 64).  Who pops the list:
-//   * HELPER workgroups (block ids behind the screening ones, a fixed few) that own no maps: they poll the list from
-//     one lane every ~2 us (s_sleep between polls: a counter word serves ~88 atomics per us chip-wide, so the pollers
+//   * HELPER workgroups (block ids behind the screening ones: 64 - 256, an eighth of the screening workgroups) that own
+//     no maps: they poll the list from one lane every 2 - 8 us (s_sleep between polls: a counter word serves ~88 atomics per us chip-wide, so the pollers
 //     must stay far below that or they starve the workgroups that do the work -- the first version of this kernel had
 //     every workgroup pop and 136 - 256 helpers poll back to back: 7 ms per launch), so a plateau map found 3 us into
 //     the launch is decoded beside the screening instead of after it;
@@ -746,15 +746,17 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 //     whatever is left: by then every push has happened, so results never depend on a helper having run (helpers give
 //     up after a bounded number of polls; speed only, never correctness).
 // The other screening workgroups touch the list with exactly one atomic (their arrival).
-// A flat map is recognised EARLY where possible (many pixels at the map's maximum right after the load: the clamp's
-// plateau) and pushed before the float32 passes; maps that only turn out flat in the screen are pushed then.
+// (An EARLY flat-map test on the raw map -- "n pixels at the map's maximum" right after the load, so that helpers can
+// start 12 us sooner -- was tried with n = 12 and n = (2r + 1)^2 and removed: a saturated blob of that many pixels
+// rarely holds a whole all-maximum kernel window, the screen settles such maps with one or two candidates, and the test
+// handed a third of the bench model's maps to the slow path: 0.7 - 0.8 ms per bs-64 launch.)
 // List protocol (ints in the workspace, all zero between launches: the launch returns them to zero itself, so no memset
 // node is needed; the caller zeroes the workspace once when it allocates it): [0] pushed, [1] taken, [2] screening
 // workgroups done, [3] leavers (helpers + the last screening workgroup), [4 ..] slots holding map + 1.  Push: reserve a
 // slot (atomic add), write it (agent-scope store), drain (vmcnt 0) before the workgroup reports itself done.  Pop: CAS
 // on `taken`, then wait for the slot to turn non-zero (its writer is two instructions behind its reservation) and clear
-// it.  Every access is an agent-scope atomic (sc1: served by memory, not by an XCD-private L2 line), the payload is a
-// 4-byte index, the heatmaps themselves are inputs nobody writes.  The last leaver zeroes the four counters: only
+// it.  Every access is an agent-scope atomic read-modify-write (see wl_read), the payload is a 4-byte index, the
+// heatmaps themselves are inputs nobody writes.  The last leaver zeroes the four counters: only
 // helpers and the last screening workgroup ever read them, and all of those have left by then.
 // (A wave-local exact path for flat maps -- row chains shared through an LDS ring -- was built in round 2 and measured
 // at 150 us per 64-crop batch of random-weight heatmaps: one wave's float64 chains are latency-bound.)
@@ -914,34 +916,45 @@ __device__ __forceinline__ double dwv_col_chain(double t, int base, int T, const
   return c;
 }
 
-// ---- work list in the workspace (see the protocol above); every access agent-scope, relaxed
-__device__ __forceinline__ int wl_load(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void wl_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ---- work list in the workspace (see the protocol above).  Every access is an agent-scope atomic READ-MODIFY-WRITE,
+// reads included (fetch_add of 0): RMWs execute at the memory side and return the current value wherever the asking
+// workgroup runs.  An `sc1` LOAD is served by the asking XCD's L2 and went stale here: a helper that had polled the
+// (then empty) counters kept reading its L2's copy of that line after other XCDs' workgroups had pushed -- helpers never
+// saw the work (the last screening workgroup decoded all 54 flat maps of a bs-64 batch alone: 1 ms), and a CAS loop fed
+// by such loads can spin forever on an expected value that is no longer there.
+__device__ __forceinline__ int wl_read(int *p) {
+  return __hip_atomic_fetch_add(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wl_store(int *p, int v) {
+  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void wl_push(int *ws, int map) {          // one lane
   const int i = __hip_atomic_fetch_add(ws, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   wl_store(ws + 4 + i, map + 1);
 }
-constexpr int WL_POLL_LIMIT = 2048;        // helper polls (~2 us apart) before it gives up: ~4 ms
-constexpr int WL_HELPERS = 64;             // helper workgroups per launch
+constexpr int WL_POLL_LIMIT = 2048;        // helper polls (2 - 8 us apart) before it gives up: 4 - 16 ms
+constexpr int WL_HELPERS_MIN = 64, WL_HELPERS_MAX = 256;   // helper workgroups per launch: n_screen / 8 within these bounds
 // one lane of a helper or of the last screening workgroup: the next listed map, or -1 when there is nothing (more) to do
 __device__ __forceinline__ int wl_pop(int *ws, bool helper, int n_screen) {
   for (int polls = 0;;) {
-    const int done = wl_load(ws + 2);
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);           // `done` is read BEFORE the counters it vouches for
-    const int t = wl_load(ws + 1), pushed = wl_load(ws + 0);
-    if (t < pushed) {
+    const int done = wl_read(ws + 2);                  // read BEFORE the counters it vouches for (RMWs of one lane
+    int t = wl_read(ws + 1);                           // complete in order: each returns before the next is issued)
+    const int pushed = wl_read(ws + 0);
+    while (t < pushed) {
       int expect = t;
       if (__hip_atomic_compare_exchange_strong(ws + 1, &expect, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT)) {
         int v = 0;
-        for (int w = 0; w < (1 << 20) && (v = wl_load(ws + 4 + t)) == 0; ++w) __builtin_amdgcn_s_sleep(2);
+        for (int w = 0; w < (1 << 16) && (v = wl_read(ws + 4 + t)) == 0; ++w) __builtin_amdgcn_s_sleep(2);
         wl_store(ws + 4 + t, 0);
         return v - 1;                                  // (-1 only if the writer vanished: nothing to decode)
       }
-      continue;                                        // somebody else took it: look again
+      t = expect;                                      // somebody else took it: the CAS returned the current value
     }
     if (!helper || done >= n_screen || ++polls > WL_POLL_LIMIT) return -1;
-    __builtin_amdgcn_s_sleep(64);                      // 64 x 64 clocks ~ 2 us
+    // ~2 us between polls with 64 helpers, ~8 us with 256: together they stay below ~100 RMWs per us on three words
+    const int naps = (int)(gridDim.x - n_screen) > 128 ? 4 : 1;
+    for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(64);       // 64 x 64 clocks ~ 2 us each
   }
 }
 
@@ -1001,25 +1014,6 @@ __device__ __forceinline__ void wave_decode_map(
     return;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the map is in LDS (this wave's own buffer)
-  if (finite && gmax > gmin) {
-    // early flat-map test: a clamped plateau shows as many pixels AT the map's maximum.  Such a map will not come out of
-    // the screen with <= DWV_MAXCAND candidates, so it is handed over now, before the float32 passes (a scheduling
-    // guess only: a wrong guess either way costs time, never the result)
-    int at_max = 0;
-#pragma unroll
-    for (int i = 0; i < G::NLD; ++i) {
-      const int e = 4 * (i * 64 + lane), y = e / W, x = e - y * W;
-      const float4 t = *reinterpret_cast<const float4 *>(buf + y * G::RS + x);
-      at_max += (t.x == gmax) + (t.y == gmax) + (t.z == gmax) + (t.w == gmax);
-    }
-#pragma unroll
-    for (int o_ = 32; o_ > 0; o_ >>= 1) at_max += __shfl_xor(at_max, o_, 64);
-    if (at_max > 12) {
-      if (lane == 0) wl_push(ws, map);
-      return;
-    }
-  }
-
   DWS(1);
   int cand_r[(DWV_MAXCAND + 63) / 64];                       // candidate ci lives in lane ci % 64 (register, not LDS:
   cand_r[0] = 0;                                             // the buffer still holds the convolved map while they are found)
@@ -1328,14 +1322,28 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   // wins (maps larger than 4096 pixels); flag PP_DECODE_SCREEN forces it everywhere, PP_DECODE_ALL_PIXEL never.
   // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288), when the caller passed the (zeroed)
   // workspace pp_decode_workspace_bytes asks for (without one: the workgroup-per-map kernels below)
-  PP_REQUIRE((flags & ~(PP_DECODE_NO_WAVE | PP_DECODE_SCREEN | PP_DECODE_ALL_PIXEL)) == 0, "pp_decode_f32: bad flags %d", flags);
+  PP_REQUIRE((flags & ~(PP_DECODE_NO_WAVE | PP_DECODE_SCREEN | PP_DECODE_ALL_PIXEL | PP_DECODE_NO_HELPERS | PP_DECODE_WAVE)) == 0,
+             "pp_decode_f32: bad flags %d", flags);
   const bool exact_all = (flags & PP_DECODE_ALL_PIXEL) != 0;
-  if (!out_conv && !(flags & PP_DECODE_NO_WAVE) && !exact_all && workspace && ((uintptr_t)heatmaps & 15) == 0 &&
+  // Batches of at most two rounds of the all-pixel kernel's resident workgroups (3 per CU at 64x48, 1 at 96x72) take that
+  // kernel: one launch, 22 - 24 us at bs 64 x 17 whatever the maps hold, where the wave kernel needs 20 - 25 us on peaked
+  // maps and 30 on the bench model's plateau-ridden ones (its flat maps wait for a helper workgroup).  Above that the
+  // wave kernel wins by 2.4x (B = 1024: 99 vs 232 us).  PP_DECODE_WAVE forces the wave kernel at any size.
+  static int ncu_ = 0;                       // (one device class per process; a wrong count only moves the cross-over)
+  if (ncu_ == 0) {
+    int dev_w = 0, n = 0;
+    if (hipGetDevice(&dev_w) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_w) != hipSuccess || n <= 0)
+      n = 256;
+    ncu_ = n;
+  }
+  const long long small_batch = 2ll * ncu_ * (H == 64 ? 3 : 1);
+  const bool wave_wanted = (flags & PP_DECODE_WAVE) || maps > small_batch;
+  if (!out_conv && !(flags & PP_DECODE_NO_WAVE) && wave_wanted && !exact_all && workspace && ((uintptr_t)heatmaps & 15) == 0 &&
       ((uintptr_t)workspace & 3) == 0 && wave_geometry(H, W)) {
     int *ws = reinterpret_cast<int *>(workspace);
     auto launch = [&](auto kern, int nwv, int lds) -> int {
       const int n_screen = cdiv(maps, nwv);
-      const int helpers = WL_HELPERS;
+      const int helpers = (flags & PP_DECODE_NO_HELPERS) ? 0 : std::min(WL_HELPERS_MAX, std::max(WL_HELPERS_MIN, n_screen / 8));
       static thread_local unsigned long long attr_mask3[2] = {0, 0};
       int dev3 = 0;
       if (lds > 48 * 1024 && attr_needed(attr_mask3[H == 64 ? 0 : 1], dev3))

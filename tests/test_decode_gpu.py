@@ -134,10 +134,17 @@ def test_edge_maps_zero_flat_ties_negative_nan(pp):
     assert np.isnan(got_c[7]).any()
     np.testing.assert_array_equal(np.isnan(got_c[7]), np.isnan(want_c[7]))
     np.testing.assert_array_equal(got_l[7], want_l[7])
-    # the same maps through the default (candidate-screened, wave-per-map) decode, which returns no convolved map
-    fast_l, fast_v = pp.get_heatmap_expected_value(hm, sig)
-    np.testing.assert_array_equal(fast_l, got_l)
-    np.testing.assert_array_equal(fast_v, got_v)
+    # the same maps through the default decode (no convolved map returned) and through the wave-per-map kernel (its flat
+    # and NaN maps take the in-launch work list), twice (the list cleans itself up), with and without helper workgroups
+    from probpose_pytorch_amd import _lib, heatmap as hmod
+    for flags in (0, _lib.DECODE_WAVE, _lib.DECODE_WAVE, _lib.DECODE_WAVE | _lib.DECODE_NO_HELPERS):
+        hmod.DECODE_FLAGS = flags
+        try:
+            fast_l, fast_v = pp.get_heatmap_expected_value(hm, sig)
+        finally:
+            hmod.DECODE_FLAGS = 0
+        np.testing.assert_array_equal(fast_l, got_l)
+        np.testing.assert_array_equal(fast_v, got_v)
 
 
 def test_empty_batch(pp):
@@ -212,7 +219,8 @@ def test_decode_c_entry_without_workspace_takes_the_workgroup_kernels(pp):
         ws = torch.zeros((int(L.pp_decode_workspace_bytes(B, K, H, W)),), dtype=torch.uint8, device="cuda")
         rc = L.pp_decode_f32(_lib.ptr(hm), None, None, None, None, B, K, H, W, _lib.ptr(taps), _lib.ptr(radius),
                              float(W - 1), float(H - 1), 192.0, 256.0, _lib.ptr(kpts), _lib.ptr(scores), _lib.ptr(locs),
-                             None, None, None, None, _lib.ptr(ws) if with_ws else None, 0, _lib.stream_ptr())
+                             None, None, None, None, _lib.ptr(ws) if with_ws else None, _lib.DECODE_WAVE if with_ws else 0,
+                             _lib.stream_ptr())
         _lib.check(rc, "pp_decode_f32")
         res.append((kpts.cpu().numpy(), scores.cpu().numpy(), locs.cpu().numpy()))
     for a, b in zip(*res):
@@ -333,6 +341,11 @@ def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
         from probpose_pytorch_amd import _lib, heatmap as hmod
         monkeypatch.setattr(hmod, "DECODE_FLAGS", 0)
         legs = {"default": codec.decode(pred)}
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_WAVE)       # the wave-per-map kernel also at small batch sizes
+        legs["wave"] = codec.decode(pred)
+        legs["wave again"] = codec.decode(pred)                            # (its work list cleaned itself up)
+        monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_WAVE | _lib.DECODE_NO_HELPERS)
+        legs["wave, no helpers"] = codec.decode(pred)
         monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN)   # workgroup-per-map screened form
         legs["screened"] = codec.decode(pred)
         monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_ALL_PIXEL)

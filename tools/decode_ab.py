@@ -28,7 +28,8 @@ for (B, K, H, W, sig) in ((64, 17, 64, 48, orc.COCO17_SIGMAS), (256, 17, 64, 48,
     L.pp_decode_workspace_bytes.restype = C.c_size_t
     nws = L.pp_decode_workspace_bytes(B, K, H, W)
     ws = torch.zeros((max(nws, 16),), dtype=torch.uint8, device="cuda")
-    MODES = {"default": 0, "wg screened": _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN, "all-pixel f64": _lib.DECODE_ALL_PIXEL}
+    MODES = {"default": 0, "wave-per-map": _lib.DECODE_WAVE, "wg screened": _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN,
+             "all-pixel f64": _lib.DECODE_ALL_PIXEL}
 
     def call(flags=0):
         rc = L.pp_decode_f32(hm.data_ptr(), None, None, None, None, B, K, H, W, taps.data_ptr(), radius.data_ptr(),

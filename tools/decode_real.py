@@ -36,10 +36,12 @@ from probpose_pytorch_amd import _lib, heatmap as hmod
 
 res = {}
 for rnd in range(5):                 # interleaved rounds, medians
-    for name, flags in (("default (wave-per-map, one launch)", 0), ("workgroup-per-map screened", _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN),
+    for name, flags in (("default", 0), ("wave-per-map (one launch, helpers)", _lib.DECODE_WAVE),
+                        ("wave-per-map, no helper workgroups", _lib.DECODE_WAVE | _lib.DECODE_NO_HELPERS),
                         ("all-pixel float64", _lib.DECODE_ALL_PIXEL)):
         hmod.DECODE_FLAGS = flags
         res.setdefault(name, []).append(t(lambda: codec.probmap.decode_device(hm)))
 hmod.DECODE_FLAGS = 0
 for name, v in res.items():
     print(f"{name:38s} model heatmaps {tuple(hm.shape)}: {sorted(v)[len(v) // 2]:8.1f} us (Python call + launch included)", flush=True)
+

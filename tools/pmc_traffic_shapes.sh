@@ -3,7 +3,8 @@
 set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-for SHAPE in ${PP_SHAPES:-"qkv 12288 2304 768 3" "proj 12288 768 768 3 resid" "fc1 12288 3072 768 3" "fc1_t9 12288 3072 768 9" "fc2 12288 768 3072 3 resid"}; do
+# (name M N K tile [resid]): the tiles the round-3 tuner picks, plus the runner-up of the wide-N shapes
+for SHAPE in "qkv_t13 12288 2304 768 13" "qkv_t6 12288 2304 768 6" "proj_t6 12288 768 768 6 resid" "fc1_t9 12288 3072 768 9" "fc1_t7 12288 3072 768 7" "fc2_t6 12288 768 3072 6 resid"; do
   set -- $SHAPE
   NAME=$1; shift
   M=$1; N=$2; K=$3; T=$4; R=${5:-}
@@ -18,7 +19,7 @@ def avg(c):
     v = []
     for f in glob.glob(f"{root}/pmcs_{name}_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if "gemm" in r["Kernel_Name"] and r["Counter_Name"] == c:
                 v.append(float(r["Counter_Value"]))
     v = v[1:] or v          # drop the cold first launch
     return sum(v) / len(v) * 1024
