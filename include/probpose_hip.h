@@ -66,8 +66,9 @@ const char *pp_last_error(void);
 int pp_device_ok(void);
 
 /* ------------------------------------------------------------------------
- * Fused decode.  Replaces, in one launch per batch (64x48 and 96x72 maps with a workspace, and every map that fits LDS;
- * maps beyond LDS -- e.g. 256x256 -- take three launches through a global-memory image):
+ * Fused decode.  Replaces, in one launch per batch (every map that fits LDS, at batch sizes up to ~1 536 maps of 64x48 /
+ * ~512 of 96x72; larger 64x48 / 96x72 batches take two launches -- one wave per map, then the few flat maps it hands
+ * over -- and maps beyond LDS, e.g. 256x256, three launches through a global-memory image):
  *   Codec.decode            probpose/codec.py:249-263
  *   ProbMap.decode          probpose/codec.py:214-239
  *   get_heatmap_expected_value + _get_subpixel_maximums
@@ -85,10 +86,11 @@ int pp_device_ok(void);
  * (prob,vis,oks passthrough), err f64 [B,K] (= err / sqrt(H^2+W^2)),
  * conv f32 [B,K,H,W] (return_heatmap=True), packed f64 [B,K,7] = (kpt x, kpt y,
  * score, prob, vis, oks, err) per keypoint: the record the multi-GPU all-gather ships.
- * workspace: pp_decode_workspace_bytes() bytes, 4-byte aligned: a (B*K + 4)-int work list for 64x48 / 96x72 maps (the
- * fast path; NULL selects the workgroup-per-map kernels instead) which the caller ZEROES ONCE when it allocates it (every
- * launch returns it to zero itself) and must not share between launches that may run concurrently; 0 for other maps that
- * fit in LDS; a float64 + float32 image of the batch for maps that do not.
+ * workspace: pp_decode_workspace_bytes() bytes, 4-byte aligned: a (B*K + 2)-int hand-over list for 64x48 / 96x72 maps
+ * (the wave-per-map path; NULL selects the workgroup-per-map kernels instead) which the caller ZEROES ONCE when it
+ * allocates it (every call returns its two counters to zero itself: no memset or reset launch) and must not share
+ * between calls that may run concurrently; 0 for other maps that fit in LDS; a float64 + float32 image of the batch for
+ * maps that do not.
  * flags: 0 = the default form per map size and batch size (64x48 / 96x72: the all-pixel kernel up to ~1 536 / ~512
  * maps, the wave-per-map kernel above); PP_DECODE_NO_WAVE / PP_DECODE_SCREEN / PP_DECODE_ALL_PIXEL select the
  * other implementations (A/B measurements and the equivalence tests: all forms return identical numbers).
@@ -96,10 +98,8 @@ int pp_device_ok(void);
 #define PP_DECODE_NO_WAVE 1             /* not the wave-per-map kernel (64x48 / 96x72 maps)                  */
 #define PP_DECODE_SCREEN 2              /* the workgroup-per-map screened kernel on every map that fits LDS  */
 #define PP_DECODE_ALL_PIXEL 4           /* float64 convolution of every pixel (the round-1 kernel)          */
-#define PP_DECODE_WAVE 16               /* the wave-per-map kernel at any batch size (default: above two rounds of the
+#define PP_DECODE_WAVE 16               /* the wave-per-map path at any batch size (default: above two rounds of the
                                            all-pixel kernel's resident workgroups, ~1 536 maps of 64x48)      */
-#define PP_DECODE_NO_HELPERS 8          /* wave-per-map kernel without helper workgroups (the last screening workgroup
-                                           decodes every listed map: measurements only)                       */
 size_t pp_decode_workspace_bytes(int B, int K, int H, int W);
 int pp_decode_f32(const float *heatmaps, const float *prob, const float *vis,
                   const float *oks, const float *err, int B, int K, int H, int W,

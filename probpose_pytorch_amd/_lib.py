@@ -12,7 +12,7 @@ PP_F32, PP_BF16, PP_FP8 = 0, 1, 2
 PP_MAX_RADIUS = 9
 PP_MAX_TAPS = 2 * PP_MAX_RADIUS + 1
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_ROWBIAS, EPI_HEATMAP = 1, 2, 4, 8, 16, 32, 64
-DECODE_NO_WAVE, DECODE_SCREEN, DECODE_ALL_PIXEL, DECODE_NO_HELPERS, DECODE_WAVE = 1, 2, 4, 8, 16
+DECODE_NO_WAVE, DECODE_SCREEN, DECODE_ALL_PIXEL, DECODE_WAVE = 1, 2, 4, 16
 EPI_HEADMAJOR = 4096
 EPI_OUT_FP8, EPI_NOCLAMP, EPI_FUSE_FINAL = 512, 1024, 2048      # 128 / 256: retired (LayerNorm fusion, round 1)
 

@@ -734,30 +734,17 @@ __global__ __launch_bounds__(DF_THREADS, DF_KEEP <= 3 ? 5 : 4) void decode_scree
 //      the column chain; then the four neighbours of the winner in one more round of 3T + 2 row chains; finalize()
 //      on lane 0.
 // Non-finite maps and flat maps (clamped plateaus: more than DWV_MAXCAND candidates) are not settled by a wave: it
-// pushes the map onto a work list in the workspace and WHOLE WORKGROUPS of the same launch decode those maps with the
-// all-pixel float64 algorithm (decode_lds_map) -- one launch, no count-reset kernel, no follow-up kernel (round 2 ran
-// three launches: 5 + 21 + 14 us at bs 64).  Who pops the list:
-//   * HELPER workgroups (block ids behind the screening ones: 64 - 256, an eighth of the screening workgroups) that own
-//     no maps: they poll the list from one lane every 2 - 8 us (s_sleep between polls: a counter word serves ~88 atomics per us chip-wide, so the pollers
-//     must stay far below that or they starve the workgroups that do the work -- the first version of this kernel had
-//     every workgroup pop and 136 - 256 helpers poll back to back: 7 ms per launch), so a plateau map found 3 us into
-//     the launch is decoded beside the screening instead of after it;
-//   * the LAST screening workgroup to finish (it knows from the counter every screening workgroup bumps once) drains
-//     whatever is left: by then every push has happened, so results never depend on a helper having run (helpers give
-//     up after a bounded number of polls; speed only, never correctness).
-// The other screening workgroups touch the list with exactly one atomic (their arrival).
-// (An EARLY flat-map test on the raw map -- "n pixels at the map's maximum" right after the load, so that helpers can
-// start 12 us sooner -- was tried with n = 12 and n = (2r + 1)^2 and removed: a saturated blob of that many pixels
-// rarely holds a whole all-maximum kernel window, the screen settles such maps with one or two candidates, and the test
-// handed a third of the bench model's maps to the slow path: 0.7 - 0.8 ms per bs-64 launch.)
-// List protocol (ints in the workspace, all zero between launches: the launch returns them to zero itself, so no memset
-// node is needed; the caller zeroes the workspace once when it allocates it): [0] pushed, [1] taken, [2] screening
-// workgroups done, [3] leavers (helpers + the last screening workgroup), [4 ..] slots holding map + 1.  Push: reserve a
-// slot (atomic add), write it (agent-scope store), drain (vmcnt 0) before the workgroup reports itself done.  Pop: CAS
-// on `taken`, then wait for the slot to turn non-zero (its writer is two instructions behind its reservation) and clear
-// it.  Every access is an agent-scope atomic read-modify-write (see wl_read), the payload is a 4-byte index, the
-// heatmaps themselves are inputs nobody writes.  The last leaver zeroes the four counters: only
-// helpers and the last screening workgroup ever read them, and all of those have left by then.
+// appends the map to a list in the workspace and the all-pixel float64 kernel (decode_lds_list_kernel, 512 threads per
+// map) that follows on the stream decodes exactly those maps; the list resets itself there (no reset launch).
+// Round 3 first tried to keep that work INSIDE the wave kernel's launch (helper workgroups polling an in-launch work list,
+// the last screening workgroup draining it).  It was correct and it lost: (1) `sc1` loads of the list counters went
+// stale across XCDs (helpers that had polled the empty list never saw pushes), so every read had to become an atomic
+// read-modify-write; (2) 64 - 256 pollers on three counter words (a word serves ~88 atomics per us chip-wide) plus one
+// arrival atomic per screening workgroup cost the launch 5 - 10 % at B = 1024; (3) helpers are the last block ids, so they
+// start when the screening is nearly over, and a 256-thread workgroup decodes a flat map in 12 us where the 512-thread
+// list kernel needs 8: on the bench model's heatmaps (5 % flat maps) 588 us per 256 crops against 69 for the all-pixel
+// kernel alone.  An EARLY flat-map test on the raw map ("n pixels at the maximum", n = 12 or (2r + 1)^2) handed a third of
+// those maps to the slow path (a saturated blob rarely holds a whole all-maximum kernel window).  All of it was removed.
 // (A wave-local exact path for flat maps -- row chains shared through an LDS ring -- was built in round 2 and measured
 // at 150 us per 64-crop batch of random-weight heatmaps: one wave's float64 chains are latency-bound.)
 // ---------------------------------------------------------------------------
@@ -916,47 +903,10 @@ __device__ __forceinline__ double dwv_col_chain(double t, int base, int T, const
   return c;
 }
 
-// ---- work list in the workspace (see the protocol above).  Every access is an agent-scope atomic READ-MODIFY-WRITE,
-// reads included (fetch_add of 0): RMWs execute at the memory side and return the current value wherever the asking
-// workgroup runs.  An `sc1` LOAD is served by the asking XCD's L2 and went stale here: a helper that had polled the
-// (then empty) counters kept reading its L2's copy of that line after other XCDs' workgroups had pushed -- helpers never
-// saw the work (the last screening workgroup decoded all 54 flat maps of a bs-64 batch alone: 1 ms), and a CAS loop fed
-// by such loads can spin forever on an expected value that is no longer there.
-__device__ __forceinline__ int wl_read(int *p) {
-  return __hip_atomic_fetch_add(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wl_store(int *p, int v) {
-  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wl_push(int *ws, int map) {          // one lane
-  const int i = __hip_atomic_fetch_add(ws, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  wl_store(ws + 4 + i, map + 1);
-}
-constexpr int WL_POLL_LIMIT = 2048;        // helper polls (2 - 8 us apart) before it gives up: 4 - 16 ms
-constexpr int WL_HELPERS_MIN = 64, WL_HELPERS_MAX = 256;   // helper workgroups per launch: n_screen / 8 within these bounds
-// one lane of a helper or of the last screening workgroup: the next listed map, or -1 when there is nothing (more) to do
-__device__ __forceinline__ int wl_pop(int *ws, bool helper, int n_screen) {
-  for (int polls = 0;;) {
-    const int done = wl_read(ws + 2);                  // read BEFORE the counters it vouches for (RMWs of one lane
-    int t = wl_read(ws + 1);                           // complete in order: each returns before the next is issued)
-    const int pushed = wl_read(ws + 0);
-    while (t < pushed) {
-      int expect = t;
-      if (__hip_atomic_compare_exchange_strong(ws + 1, &expect, t + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT)) {
-        int v = 0;
-        for (int w = 0; w < (1 << 16) && (v = wl_read(ws + 4 + t)) == 0; ++w) __builtin_amdgcn_s_sleep(2);
-        wl_store(ws + 4 + t, 0);
-        return v - 1;                                  // (-1 only if the writer vanished: nothing to decode)
-      }
-      t = expect;                                      // somebody else took it: the CAS returned the current value
-    }
-    if (!helper || done >= n_screen || ++polls > WL_POLL_LIMIT) return -1;
-    // ~2 us between polls with 64 helpers, ~8 us with 256: together they stay below ~100 RMWs per us on three words
-    const int naps = (int)(gridDim.x - n_screen) > 128 ? 4 : 1;
-    for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(64);       // 64 x 64 clocks ~ 2 us each
-  }
-}
+// hand-over list in the workspace: [0] = count, [1] = list-kernel workgroups that have read the count (its reset),
+// [2 ..] = map indices.  Pushed by single lanes of the wave kernel, consumed by decode_lds_list_kernel, the next launch
+// on the stream (a kernel boundary: plain device-scope atomics and plain loads suffice).
+__device__ __forceinline__ void wl_push(int *ws, int map) { ws[2 + atomicAdd(ws, 1)] = map; }
 
 template <int H, int W>
 __device__ __forceinline__ void wave_decode_map(
@@ -1162,59 +1112,45 @@ __device__ __forceinline__ void wave_decode_map(
 #undef DWS
 }
 
-template <int H, int W, int NWV>
-constexpr __host__ __device__ int wave_kernel_image_bytes() {
-  constexpr int allpix = H * W * 8 + H * (4 * ((W + 3) / 4) + 2 * DEC_HALO) * 4;
-  constexpr int waves = NWV * WaveGeom<H, W>::BUF * 4;
-  return ((waves > allpix ? waves : allpix) + 15) & ~15;
-}
-template <int H, int W, int NWV>
-constexpr int wave_kernel_lds_bytes() { return wave_kernel_image_bytes<H, W, NWV>() + NWV * (int)sizeof(Best) + 16; }
-
-// NWV waves (= maps) per screening workgroup; MINW = waves per SIMD the register budget is cut for.
+// NWV waves (= maps) per workgroup; MINW = waves per SIMD the register budget is cut for.
 template <int H, int W, int NWV, int MINW>
 __global__ __launch_bounds__(NWV * 64, MINW) void decode_wave_kernel(
     const float *__restrict__ heatmaps, const float *prob, const float *vis, const float *oks, const float *err, int B,
     int K, const double *__restrict__ taps, const int *__restrict__ radius, double den_x, double den_y, double in_w,
-    double in_h, DecodeOut o, int *__restrict__ ws, int n_screen) {
+    double in_h, DecodeOut o, int *__restrict__ ws) {
   using G = WaveGeom<H, W>;
-  // phase 1: one map per wave in its own buffer; phase 2: the same bytes hold the all-pixel image of a listed map
-  // (all LDS is dynamic: a static array in front of it would shift the 16-byte alignment of the images)
-  extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
-  float *lds = reinterpret_cast<float *>(dyn_lds);
-  Best *red = reinterpret_cast<Best *>(dyn_lds + wave_kernel_image_bytes<H, W, NWV>());
-  int &s_item = *reinterpret_cast<int *>(red + NWV);
+  __shared__ __attribute__((aligned(16))) float lds[NWV][G::BUF];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool helper = (int)blockIdx.x >= n_screen;
-  bool pops = helper;                                       // does this workgroup take part in draining the list?
-  if (!helper) {
-    const int map = blockIdx.x * NWV + wave;
-    if (map < B * K)
-      wave_decode_map<H, W>(map, lds + wave * G::BUF, heatmaps, prob, vis, oks, err, B, K, taps, radius, den_x, den_y,
-                            in_w, in_h, o, ws);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's push (if any) is written through
-    __syncthreads();
-    if (threadIdx.x == 0)
-      s_item = __hip_atomic_fetch_add(ws + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_screen - 1;
-    __syncthreads();
-    pops = s_item != 0;                                     // the last screening workgroup: every push is in by now
-    __syncthreads();
-    if (!pops) return;                                      // everybody else: one atomic and out
+  const int map = blockIdx.x * NWV + wave;
+  if (map >= B * K) return;                          // whole waves leave; nothing synchronises across waves
+  wave_decode_map<H, W>(map, lds[wave], heatmaps, prob, vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, ws);
+}
+
+// The all-pixel float64 decode over the LIST the wave kernel left (the launch before this one on the stream).  The grid
+// is fixed (graph-capturable); workgroups stride over the list and leave at once when it is empty.  The list resets
+// itself: every workgroup reads the count, then arrives on a second counter; the last to arrive -- every workgroup has
+// read the count by then -- zeroes both.  The caller zeroes the workspace once when it allocates it; no memset node, no
+// reset kernel (round 2 spent 5 us per batch on one).
+__global__ __launch_bounds__(DEC_THREADS) void decode_lds_list_kernel(
+    int *__restrict__ list, const float *__restrict__ heatmaps, const float *prob, const float *vis,
+    const float *oks, const float *err, int B, int K, int H, int W, const double *__restrict__ taps,
+    const int *__restrict__ radius, double den_x, double den_y, double in_w, double in_h, DecodeOut o) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ Best red[DEC_THREADS / 64];
+  __shared__ int s_n;
+  if (threadIdx.x == 0) {
+    s_n = __hip_atomic_load(list, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(list + 1, 1) == (int)gridDim.x - 1) {      // everybody has read the count
+      __hip_atomic_store(list, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(list + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-  for (;;) {
-    if (threadIdx.x == 0) s_item = wl_pop(ws, helper, n_screen);
-    __syncthreads();
-    const int it = s_item;
-    __syncthreads();
-    if (it < 0) break;
-    decode_lds_map<NWV * 64>(it, reinterpret_cast<char *>(lds), red, heatmaps, prob, vis, oks, err, B, K, H, W, taps,
-                             radius, den_x, den_y, in_w, in_h, o, nullptr);
-    __syncthreads();
-  }
-  // leavers = the helpers + the last screening workgroup: the only readers of the counters.  The last one out zeroes them.
-  if (threadIdx.x == 0 &&
-      __hip_atomic_fetch_add(ws + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - n_screen) {
-    wl_store(ws + 0, 0); wl_store(ws + 1, 0); wl_store(ws + 2, 0); wl_store(ws + 3, 0);
+  __syncthreads();
+  const int n = s_n;
+  for (int b = blockIdx.x; b < n; b += gridDim.x) {
+    decode_lds_map<DEC_THREADS>(list[2 + b], smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x,
+                                den_y, in_w, in_h, o, nullptr);
+    __syncthreads();                     // the next map reuses the LDS image and the reduction slots
   }
 }
 
@@ -1294,7 +1230,7 @@ static bool wave_geometry(int H, int W) { return (H == 64 && W == 48) || (H == 9
 }  // namespace pp
 
 extern "C" size_t pp_decode_workspace_bytes(int B, int K, int H, int W) {
-  if (pp::wave_geometry(H, W)) return ((size_t)B * K + 4) * sizeof(int);   // work list of the wave-per-map path (zeroed once by the caller)
+  if (pp::wave_geometry(H, W)) return ((size_t)B * K + 2) * sizeof(int);   // hand-over list of the wave-per-map path (zeroed once by the caller)
   if (pp::fits_lds(H, W)) return 0;
   return (size_t)B * K * H * W * (sizeof(double) + sizeof(float));
 }
@@ -1322,13 +1258,13 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   // wins (maps larger than 4096 pixels); flag PP_DECODE_SCREEN forces it everywhere, PP_DECODE_ALL_PIXEL never.
   // wave-per-map kernel: 64x48 maps (256x192 models) and 96x72 maps (384x288), when the caller passed the (zeroed)
   // workspace pp_decode_workspace_bytes asks for (without one: the workgroup-per-map kernels below)
-  PP_REQUIRE((flags & ~(PP_DECODE_NO_WAVE | PP_DECODE_SCREEN | PP_DECODE_ALL_PIXEL | PP_DECODE_NO_HELPERS | PP_DECODE_WAVE)) == 0,
+  PP_REQUIRE((flags & ~(PP_DECODE_NO_WAVE | PP_DECODE_SCREEN | PP_DECODE_ALL_PIXEL | PP_DECODE_WAVE)) == 0,
              "pp_decode_f32: bad flags %d", flags);
   const bool exact_all = (flags & PP_DECODE_ALL_PIXEL) != 0;
   // Batches of at most two rounds of the all-pixel kernel's resident workgroups (3 per CU at 64x48, 1 at 96x72) take that
-  // kernel: one launch, 22 - 24 us at bs 64 x 17 whatever the maps hold, where the wave kernel needs 20 - 25 us on peaked
-  // maps and 30 on the bench model's plateau-ridden ones (its flat maps wait for a helper workgroup).  Above that the
-  // wave kernel wins by 2.4x (B = 1024: 99 vs 232 us).  PP_DECODE_WAVE forces the wave kernel at any size.
+  // kernel: ONE launch, 22 - 24 us at bs 64 x 17 whatever the maps hold, where the wave kernel + its list kernel need
+  // 20 - 25 us on peaked maps and ~27 on the bench model's plateau-ridden ones.  Above that the wave kernel wins by up to
+  // 2.4x (B = 1024: 94 - 99 vs 232 us) and the second launch is noise.  PP_DECODE_WAVE forces the wave path at any size.
   static int ncu_ = 0;                       // (one device class per process; a wrong count only moves the cross-over)
   if (ncu_ == 0) {
     int dev_w = 0, n = 0;
@@ -1340,24 +1276,23 @@ extern "C" int pp_decode_f32(const float *heatmaps, const float *prob, const flo
   const bool wave_wanted = (flags & PP_DECODE_WAVE) || maps > small_batch;
   if (!out_conv && !(flags & PP_DECODE_NO_WAVE) && wave_wanted && !exact_all && workspace && ((uintptr_t)heatmaps & 15) == 0 &&
       ((uintptr_t)workspace & 3) == 0 && wave_geometry(H, W)) {
-    int *ws = reinterpret_cast<int *>(workspace);
-    auto launch = [&](auto kern, int nwv, int lds) -> int {
-      const int n_screen = cdiv(maps, nwv);
-      const int helpers = (flags & PP_DECODE_NO_HELPERS) ? 0 : std::min(WL_HELPERS_MAX, std::max(WL_HELPERS_MIN, n_screen / 8));
-      static thread_local unsigned long long attr_mask3[2] = {0, 0};
-      int dev3 = 0;
-      if (lds > 48 * 1024 && attr_needed(attr_mask3[H == 64 ? 0 : 1], dev3))
-        PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      hipLaunchKernelGGL(kern, dim3((unsigned)(n_screen + helpers)), dim3(nwv * 64), lds, s, heatmaps, prob, vis, oks, err,
-                         B, K, taps, radius, den_x, den_y, in_w, in_h, o, ws, n_screen);
-      return 0;
-    };
-    if (H == 64) {
-      if (launch(decode_wave_kernel<64, 48, 4, 3>, 4, wave_kernel_lds_bytes<64, 48, 4>())) return -1;
-    } else {
-      if (launch(decode_wave_kernel<96, 72, 5, 2>, 5, wave_kernel_lds_bytes<96, 72, 5>())) return -1;
-    }
+    int *ws = reinterpret_cast<int *>(workspace);       // [0] count, [1] arrivals of the list kernel, [2 ..] maps
+    if (H == 64)
+      hipLaunchKernelGGL((decode_wave_kernel<64, 48, 4, 3>), dim3((unsigned)cdiv(maps, 4)), dim3(256), 0, s, heatmaps, prob,
+                         vis, oks, err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, ws);
+    else
+      hipLaunchKernelGGL((decode_wave_kernel<96, 72, 1, 2>), dim3((unsigned)maps), dim3(64), 0, s, heatmaps, prob, vis, oks,
+                         err, B, K, taps, radius, den_x, den_y, in_w, in_h, o, ws);
     PP_CHECK_LAUNCH("decode_wave_kernel");
+    const size_t lds = lds_bytes(H, W);
+    static thread_local unsigned long long attr_mask3 = 0;
+    int dev3 = 0;
+    if (lds > 64 * 1024 && attr_needed(attr_mask3, dev3))
+      PP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(decode_lds_list_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+    hipLaunchKernelGGL(decode_lds_list_kernel, dim3((unsigned)(maps < 256 ? maps : 256)), dim3(DEC_THREADS), lds, s, ws,
+                       heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x, den_y, in_w, in_h, o);
+    PP_CHECK_LAUNCH("decode_lds_list_kernel");
     return 0;
   }
   const bool want_screen = (flags & PP_DECODE_SCREEN) || (long long)H * W > 4096;

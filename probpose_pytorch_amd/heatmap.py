@@ -58,8 +58,8 @@ def _device_taps(K, H, W, sigmas, device):
 # the equivalence tests; every form returns identical numbers)
 DECODE_FLAGS = 0
 
-# zeroed work-list buffers of the wave-per-map kernel, one per (device, stream): allocated and zeroed once, every launch
-# leaves them zeroed (include/probpose_hip.h), the address stays stable for graph replay
+# zeroed hand-over lists of the wave-per-map path, one per (device, stream): allocated and zeroed once, every call
+# leaves their counters zeroed (include/probpose_hip.h), the address stays stable for graph replay
 _DECODE_WS: dict = {}
 
 
@@ -117,7 +117,7 @@ def decode_on_device(heatmaps: torch.Tensor, sigmas, *, den=None, input_size=Non
         out["conv"] = torch.empty_like(heatmaps)
     ws_bytes = L.pp_decode_workspace_bytes(B, K, H, W)
     if (H, W) in ((64, 48), (96, 72)):
-        ws = _decode_workspace(ws_bytes, dev)                # the self-cleaning work list: zeroed once, kept
+        ws = _decode_workspace(ws_bytes, dev)                # the self-resetting hand-over list: zeroed once, kept
     else:
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if ws_bytes else None
     from . import ops as _ops

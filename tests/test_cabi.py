@@ -37,8 +37,8 @@ def test_argument_validation_without_gpu(built_lib):
     rc = built_lib.pp_decode_f32(None, None, None, None, None, 1, 17, 64, 48, None, None,
                                  1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, 0, None)
     assert rc != 0 and b"null" in built_lib.pp_last_error()
-    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == (17 + 4) * 4     # work list of the wave-per-map path
-    assert built_lib.pp_decode_workspace_bytes(2, 133, 96, 72) == (2 * 133 + 4) * 4
+    assert built_lib.pp_decode_workspace_bytes(1, 17, 64, 48) == (17 + 2) * 4     # hand-over list of the wave-per-map path
+    assert built_lib.pp_decode_workspace_bytes(2, 133, 96, 72) == (2 * 133 + 2) * 4
     assert built_lib.pp_decode_workspace_bytes(1, 17, 32, 24) == 0                # fits LDS, no list
     assert built_lib.pp_decode_workspace_bytes(1, 20, 256, 256) == 20 * 256 * 256 * 12
     with pytest.raises(_lib.HipExtensionError):
@@ -78,5 +78,5 @@ def test_gemm_argument_validation_without_gpu(built_lib):
     a.residual = 0x3000
     assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tile 13" in built_lib.pp_last_error()
     rc = built_lib.pp_decode_f32(0x1000, None, None, None, None, 1, 17, 64, 48, 0x2000, 0x3000,
-                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, 64, None)
+                                 1.0, 1.0, 1.0, 1.0, None, None, None, None, None, None, None, None, 8, None)
     assert rc != 0 and b"flags" in built_lib.pp_last_error()

@@ -134,10 +134,10 @@ def test_edge_maps_zero_flat_ties_negative_nan(pp):
     assert np.isnan(got_c[7]).any()
     np.testing.assert_array_equal(np.isnan(got_c[7]), np.isnan(want_c[7]))
     np.testing.assert_array_equal(got_l[7], want_l[7])
-    # the same maps through the default decode (no convolved map returned) and through the wave-per-map kernel (its flat
-    # and NaN maps take the in-launch work list), twice (the list cleans itself up), with and without helper workgroups
+    # the same maps through the default decode (no convolved map returned) and through the wave-per-map path (its flat
+    # and NaN maps take the hand-over list), three times (the list resets itself)
     from probpose_pytorch_amd import _lib, heatmap as hmod
-    for flags in (0, _lib.DECODE_WAVE, _lib.DECODE_WAVE, _lib.DECODE_WAVE | _lib.DECODE_NO_HELPERS):
+    for flags in (0, _lib.DECODE_WAVE, _lib.DECODE_WAVE, _lib.DECODE_WAVE):
         hmod.DECODE_FLAGS = flags
         try:
             fast_l, fast_v = pp.get_heatmap_expected_value(hm, sig)
@@ -343,9 +343,7 @@ def test_screened_decode_equals_all_pixel_float64_decode(pp, monkeypatch):
         legs = {"default": codec.decode(pred)}
         monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_WAVE)       # the wave-per-map kernel also at small batch sizes
         legs["wave"] = codec.decode(pred)
-        legs["wave again"] = codec.decode(pred)                            # (its work list cleaned itself up)
-        monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_WAVE | _lib.DECODE_NO_HELPERS)
-        legs["wave, no helpers"] = codec.decode(pred)
+        legs["wave again"] = codec.decode(pred)                            # (its hand-over list reset itself)
         monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_NO_WAVE | _lib.DECODE_SCREEN)   # workgroup-per-map screened form
         legs["screened"] = codec.decode(pred)
         monkeypatch.setattr(hmod, "DECODE_FLAGS", _lib.DECODE_ALL_PIXEL)

@@ -36,8 +36,7 @@ from probpose_pytorch_amd import _lib, heatmap as hmod
 
 res = {}
 for rnd in range(5):                 # interleaved rounds, medians
-    for name, flags in (("default", 0), ("wave-per-map (one launch, helpers)", _lib.DECODE_WAVE),
-                        ("wave-per-map, no helper workgroups", _lib.DECODE_WAVE | _lib.DECODE_NO_HELPERS),
+    for name, flags in (("default", 0), ("wave-per-map + list kernel", _lib.DECODE_WAVE),
                         ("all-pixel float64", _lib.DECODE_ALL_PIXEL)):
         hmod.DECODE_FLAGS = flags
         res.setdefault(name, []).append(t(lambda: codec.probmap.decode_device(hm)))
