@@ -256,10 +256,13 @@ def cpu_baseline(cfg, sd, seconds_budget: float = 60.0):
 
 
 def parity_block(cfg, sd, model, codec, x, dtype, n_crops: int = 8, fp32_steps: int = 3):
-    """What the benchmarked dtype costs in accuracy and what the contract-meeting mode costs in speed
-    (BASELINE.json north_star: decoded keypoints / probabilities within 1e-4 of the CPU path -- met by the
-    exact-fp32 MFMA mode; bf16 / fp8 report their measured deviation).  The reference here is
-    oracle.model_forward + codec_decode on the same crops (checker only, never the thing measured)."""
+    """What the benchmarked dtype costs in accuracy and what the exact-fp32 mode costs in speed (BASELINE.json
+    north_star: decoded keypoints / probabilities within 1e-4 of the CPU path).  Measured on this workload the
+    exact-fp32 MFMA mode keeps every heatmap / auxiliary value within 1e-4 (max 4.3e-5) and 99.3 % of the keypoints
+    within 1e-4 px, the rest within 2.2e-4 px: the sub-pixel step divides by the convolved map's curvature and
+    amplifies the heatmap deviation on flat peaks (tests/test_model_gpu.py checks all 64 crops); bf16 / fp8 report
+    their measured deviation, `fp32.contract_met_1e-4_px` says which side of the contract this run fell on.  The
+    reference here is oracle.model_forward + codec_decode on the same crops (checker only, never the thing measured)."""
     from oracle import probpose_oracle as orc
     H, W = cfg["img"]
     sig = sigmas_for(cfg["K"])
@@ -275,6 +278,7 @@ def parity_block(cfg, sd, model, codec, x, dtype, n_crops: int = 8, fp32_steps: 
         return {"kpt_px_median": round(float(np.median(d)), 6), "kpt_px_p90": round(float(np.percentile(d, 90)), 6),
                 "kpt_px_max": round(float(d.max()), 6),
                 "frac_kpts_within_1e-4_px": round(float((d <= 1e-4).mean()), 4),
+                "contract_met_1e-4_px": bool((d <= 1e-4).all()),
                 "peak_moved_rate": round(float((d > 2.0).mean()), 4),      # > half a heatmap cell (4 input px)
                 "heatmap_abs_mean": round(float(hm.mean()), 7), "heatmap_abs_max": round(float(hm.max()), 6),
                 "aux_abs_max": round(max(float(np.abs(a - b).max()) for a, b in zip(dec[1:], ref[1:])), 7)}

@@ -158,9 +158,10 @@ typedef struct pp_gemm_args {
                                    issues DMA while the other runs MFMAs; bf16 / fp8 plain layers),
                                    14 = 192x192 as TWO 4-wave workgroups per CU (96x96 wave tiles, 32-deep K-tiles, 72 KB
                                    of LDS each; plain bf16 layers with bias / GELU / ReLU / f32 residual).
-                                   11-13 are kept-for-the-record experimental forms: 11 = 2x2 MFMA
-                                   waves + 4 DMA waves, 12 = hand-pipelined consumer (lab builds only), 13 = persistent
-                                   workgroups streaming several tiles with a deferred epilogue (bf16 outputs). */
+                                   13 = persistent 192x192 stream (one workgroup per CU walks its tiles as one stream of
+                                   K-tiles, the next tile's first K-tiles land under the epilogue; plain bf16 -> bf16
+                                   layers with bias / GELU / ReLU, e.g. qkv and fc1).
+                                   11, 12: round-2 experiments, removed (refused). */
   float out_scale;              /* PP_EPI_OUT_FP8: 1 / (scale of the fp8 output tensor) */
   int splitk;                   /* 0 / 1 = off.  S > 1: the launch computes S partial products per batch entry, split s
                                    over the K range [s * Kd, (s + 1) * Kd) (Kd = the PER-SPLIT depth): operands advance
