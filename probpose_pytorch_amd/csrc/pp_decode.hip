@@ -906,7 +906,12 @@ __device__ __forceinline__ double dwv_col_chain(double t, int base, int T, const
 // hand-over list in the workspace: [0] = count, [1] = list-kernel workgroups that have read the count (its reset),
 // [2 ..] = map indices.  Pushed by single lanes of the wave kernel, consumed by decode_lds_list_kernel, the next launch
 // on the stream (a kernel boundary: plain device-scope atomics and plain loads suffice).
-__device__ __forceinline__ void wl_push(int *ws, int map) { ws[2 + atomicAdd(ws, 1)] = map; }
+// (`maps` bounds the slot: a caller that broke the contract -- a workspace that was never zeroed -- gets wrong results for
+// the dropped maps, never an out-of-bounds write.)
+__device__ __forceinline__ void wl_push(int *ws, int map, int maps) {
+  const int i = atomicAdd(ws, 1);
+  if ((unsigned)i < (unsigned)maps) ws[2 + i] = map;
+}
 
 template <int H, int W>
 __device__ __forceinline__ void wave_decode_map(
@@ -1022,7 +1027,7 @@ __device__ __forceinline__ void wave_decode_map(
   if (ncand > DWV_MAXCAND) {
     // Flat map (a clamped plateau: hundreds of exact ties and near-ties) or non-finite map (every pixel counts): not
     // worth a wave's serial chains.  It goes on the work list of the all-pixel float64 decode (whole workgroups).
-    if (lane == 0) wl_push(ws, map);
+    if (lane == 0) wl_push(ws, map, B * K);
     return;
   }
   // 5. exact values, first-index arg-max (np.argmax semantics incl. NaN).  Row chains on lanes 0..T-1, handed to the
@@ -1146,9 +1151,9 @@ __global__ __launch_bounds__(DEC_THREADS) void decode_lds_list_kernel(
     }
   }
   __syncthreads();
-  const int n = s_n;
+  const int n = min(max(s_n, 0), B * K);              // (bounded whatever the workspace held: see wl_push)
   for (int b = blockIdx.x; b < n; b += gridDim.x) {
-    decode_lds_map<DEC_THREADS>(list[2 + b], smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x,
+    decode_lds_map<DEC_THREADS>(min(max(list[2 + b], 0), B * K - 1), smem, red, heatmaps, prob, vis, oks, err, B, K, H, W, taps, radius, den_x,
                                 den_y, in_w, in_h, o, nullptr);
     __syncthreads();                     // the next map reuses the LDS image and the reduction slots
   }
