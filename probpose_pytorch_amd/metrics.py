@@ -118,15 +118,15 @@ def pose_pck_accuracy(output, target, mask: np.ndarray, thr: float = 0.05, norma
     ``method`` 'argmax' locates peaks with get_heatmap_maximum; 'expected' is the branch in which the reference calls
     get_heatmap_expected_value WITHOUT sigmas (loss.py:820-821: a TypeError there) -- ``pose_pck_accuracy_expected``
     is that branch made callable."""
-    method = method.lower()
-    if method not in ["argmax", "expected"]:
+    how = str(method).lower()
+    if how not in ("argmax", "expected"):
         raise ValueError(f"Invalid method: {method}")
+    if how == "expected":
+        raise TypeError("get_heatmap_expected_value() missing 1 required positional argument: 'sigmas' "
+                        "(reference loss.py:820 calls it without sigmas; use pose_pck_accuracy_expected)")
     N, K, H, W = output.shape
     if K == 0:
         return None, 0, 0
-    if method == "expected":
-        raise TypeError("get_heatmap_expected_value() missing 1 required positional argument: 'sigmas' "
-                        "(reference loss.py:820 calls it without sigmas; use pose_pck_accuracy_expected)")
     p, _, _ = _argmax_device(output)
     g, _, _ = _argmax_device(target)
     hits, valid = pck_counts(p, g, mask, thr, _default_normalize(N, H, W) if normalize is None else normalize)

@@ -107,3 +107,29 @@ def test_bench_starts_its_own_ranks(monkeypatch):
         raise AssertionError("main() should have exited")
     except SystemExit as e:
         assert e.code == 17
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_launches_two_ranks_on_the_gpu_box(tmp_path):
+    """`python bench.py --gpus 2` started the way the driver starts `--gpus 1` (no launcher, no WORLD_SIZE): the parent
+    spawns its own two ranks and relays rank 0's line with n_gpus = 2, parallelism dp2, global batch 2 x 64.  On the
+    one-GPU box both ranks share the card and the collective runs over gloo (PP_BENCH_REHEARSAL=1: RCCL refuses two
+    ranks on one device), so this walks the launcher, the rendezvous, the sharded seeds, the all-gather call path and
+    the max-over-ranks timing -- everything but RCCL itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PP_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-parity", "--no-decode-scale"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 128
+    assert d["scaling"] == "weak" and d["value"] > 0
