@@ -25,11 +25,10 @@
 #include <algorithm>
 
 #include "pp_common.h"
+#include "pp_gemm_shared.h"
 
 namespace pp {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROW_BYTES = 128;                 // bytes of K per staged row
 constexpr int FUSE_MAPS = 32;                   // keypoint maps the fused final 1x1 layer serves (two 16-wide MFMA tiles)
@@ -57,10 +56,6 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define PP_ACC(dst, a, b)
 #endif
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Zero rows (W rows beyond N, zero-padding taps of the implicit convolutions) are DMA'd from a 64 KiB
 // zero region, each lane/workgroup at a different 128-B line: one shared line would funnel every
@@ -69,82 +64,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 constexpr int ZERO_REGION = 64 * 1024;
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[ZERO_REGION];
 
-struct GemmParams {
-  const char *A;
-  const char *W;
-  char *C;
-  const float *bias;
-  const float *residual;
-  const float *rowbias;
-  const int32_t *rowoff;
-  const int32_t *out_rowmap;
-  int M, N, Kd;
-  int lda, ldw, ldc;
-  int seg_len, rowbias_period;
-  long long strideA, strideW, strideC, strideBias, strideRowoff, strideRowmap;
-  int splitk;        // K splits per batch entry (grid.y = batch * splitk)
-  long long strideA_k, strideW_k, strideC_k, strideRowoff_k;
-  int epilogue;
-  int hm_K, hm_HW;
-  float hm_temperature;
-  int tiles_m, tiles_n;
-  const float *colsum;
-  float out_scale;   // fp8 output: value * out_scale is what gets rounded to e4m3
-  int blocked;       // XCD-blocked tile order (large grids) vs plain order
-  int rn;            // column tiles per XCD block (<= tiles_n, so narrow-N launches carry no empty slots)
-  int lds_epilogue;  // bf16 C tile staged through LDS and stored as whole rows
-  const char *final_w;     // PP_EPI_FUSE_FINAL: [hm_K, N] storage-dtype weights of the 1x1 heatmap layer
-  const float *final_b;    // [hm_K]
-};
 
-// LDS-DMA of 16 B per lane: LDS destination = wave-uniform byte offset (M0) + lane * 16.  Issued
-// from inline asm on purpose: hipcc cannot tell that the DMA into buffer t+1 never aliases the
-// ds_reads of buffer t and would drain vmcnt(0) in front of every fragment read, serialising the
-// prefetch behind the MFMAs.  The asm DMA is invisible to its wait-count bookkeeping; completion is
-// enforced by the explicit s_waitcnt vmcnt(0) + barrier that ends each K-step.
-__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_off_uniform) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_off_uniform)
-      : "memory");
-}
 
-__device__ __forceinline__ unsigned lds_offset_of(const void *p) {
-  return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-// bf16 epilogues only: GELU(x) = x * Phi(x) with Phi(x) ~ sigmoid(x * (c0 + c1 t + c2 t^2)), t = min(x^2, 50),
-// coefficients fitted (minimax) against the exact-erf GELU: |error| <= 3.0e-5 absolute over all x (the tanh
-// form's is 4.7e-4), i.e. below half a bf16 ulp of every output with |GELU| > 0.016 and an absolute 3e-5
-// for the rest; the output is rounded to bf16 right after.  7 VALU + exp + rcp per element instead of the 16 +
-// exp + rcp of an Abramowitz-Stegun erf: the GELU arithmetic was 15 us of a 100 us fc1 GEMM (measured).
-// The constants carry the factor -log2(e) so the sigmoid is 1 / (1 + exp2(x * p)).
-// Two elements per call: the polynomial runs on packed-fp32 instructions (v_pk_mul/fma/add_f32).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-  const f32x2 t = __builtin_elementwise_min(x * x, (f32x2){50.0f, 50.0f});
-  const f32x2 c2 = {0.001035082619637251f, 0.001035082619637251f};
-  const f32x2 c1 = {-0.10690470039844513f, -0.10690470039844513f};
-  const f32x2 c0 = {-2.300978660583496f, -2.300978660583496f};
-  const f32x2 u = x * __builtin_elementwise_fma(__builtin_elementwise_fma(c2, t, c1), t, c0);
-  const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + (f32x2){1.0f, 1.0f};
-  return x * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-}
-template <typename T>
-__device__ __forceinline__ void gelu4(float (&v)[4]) {
-  if constexpr (sizeof(T) <= 2) {
-    const f32x2 a = gelu_fast2((f32x2){v[0], v[1]}), b = gelu_fast2((f32x2){v[2], v[3]});
-    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-  }
-}
 
 // OCP e4m3 (gfx950): 4 floats -> 4 bytes, round-to-nearest-even, saturating at +-448 (NaN stays NaN)
 typedef unsigned char fp8_t;
@@ -1600,6 +1521,10 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
 #endif
 }
 
+// pp_gemm_quad.hip: tiles 15 - 17 (four waves, one per SIMD, 128x128 / 128x96 / 96x144 wave tiles)
+int gemm_quad_launch(const GemmParams &p, int cfg, dim3 grid, hipStream_t s);
+void gemm_quad_tile_shape(int cfg, int *bm, int *bn);
+
 }  // namespace pp
 
 #ifndef PP_CFG5_VS_CFG3
@@ -1694,7 +1619,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
   // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 14 && a->tile != 11 && a->tile != 12,
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 19 && a->tile != 11 && a->tile != 12,
              "pp_gemm: bad tile selector %d (11 / 12: round-2 experiments, removed)", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
@@ -1718,8 +1643,9 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
       if (c5 < best) { best = c5; cfg = 5; }
     }
   }
-  const int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
-  const int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 13 || cfg == 14) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
+  int bm = cfg == 1 ? 128 : (cfg == 5 ? 384 : (cfg == 8 ? 256 : 192));
+  int bn = cfg == 1 ? 128 : (cfg == 2 ? 96 : ((cfg == 3 || cfg == 6 || cfg == 10 || cfg == 13 || cfg == 14) ? 192 : (cfg == 7 ? 384 : ((cfg == 8 || cfg == 9) ? 256 : 128))));
+  if (cfg >= 15) gemm_quad_tile_shape(cfg, &bm, &bn);
   p.tiles_m = cdiv(a->M, bm);
   p.tiles_n = cdiv(a->N, bn);
   dim3 grid;
@@ -1743,6 +1669,18 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_REQUIRE(p.lds_epilogue && vec, "pp_gemm: PP_EPI_FUSE_FINAL runs inside the LDS epilogue: C must be 16-byte aligned "
                                       "(and N = ldc = 256)");
   hipStream_t s = (hipStream_t)stream;
+  if (cfg >= 15) {
+    // quad forms (pp_gemm_quad.hip): plain bf16 -> bf16 layers, K-tiles of 32 walked in pairs behind a 4-deep ring
+    PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && p.lds_epilogue && batch == 1 &&
+                   a->Kd % 64 == 0 && a->Kd >= 128 && (a->N & 7) == 0 &&
+                   !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | PP_EPI_HEADMAJOR | (1 << 30))),
+               "pp_gemm: tiles 15 - 19 (four-wave forms) serve plain bf16 -> bf16 GEMMs with bias / GELU / ReLU epilogues, "
+               "K >= 128");
+    if (cfg >= 18)
+      PP_REQUIRE(a->M % bm == 0 && a->N % bn == 0 && a->Kd >= 512 && (unsigned long long)a->M * a->ldc * 2 < 0xFFFFFFF0ull,
+                 "pp_gemm: tiles 18 / 19 (four-wave stream) need M %% %d == 0, N %% %d == 0, K >= 512 and C below 4 GiB", bm, bn);
+    return gemm_quad_launch(p, cfg, grid, s);
+  }
   if (cfg == 14) {
     // duo form (gemm_duo_kernel): plain bf16 layers (K a multiple of 64 like every bf16 tile; it stages 32-deep K-tiles)
     PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && batch == 1 && a->Kd % 64 == 0 &&

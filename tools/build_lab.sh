@@ -8,5 +8,5 @@ NAME=$1; shift
 mkdir -p "$ROOT/probpose_pytorch_amd/lib/exp"
 cd "$ROOT/probpose_pytorch_amd/csrc"
 hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-  -DPP_GEMM_LAB "$@" pp_gemm.hip pp_capi.hip -o "../lib/exp/$NAME.so"
+  -DPP_GEMM_LAB "$@" pp_gemm.hip pp_gemm_quad.hip pp_capi.hip -o "../lib/exp/$NAME.so"
 echo "built lib/exp/$NAME.so"

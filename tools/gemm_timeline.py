@@ -85,7 +85,7 @@ print(f"  in-kernel clock over the K-loop: median {np.median(clk_ghz):.3f} GHz (
       f"p90 {np.percentile(clk_ghz, 90):.3f}); K-loop {np.median(cyc) / (K // 64):.0f} cycles per 64-deep K-tile"
       f"{' [lda0]' if LDA0 else ''}{' [ldw0]' if LDW0 else ''}{' [batch8]' if BATCH8 else ''}{' [l2res]' if L2RES else ''}"
       f"{' [samerows]' if SAMEROWS else ''}")
-if tile == 13:
+if tile in (13, 18, 19):
     epi = np.where(live, s[:, :, 7], 0).max(axis=1)
     print(f"  persistent stream: {np.median(cyc):.0f} cycles per workgroup, of which epilogues {np.median(epi):.0f} "
           f"({np.median(epi) / np.median(cyc):.1%}); tiles per workgroup ~{M * N / 192 / 192 / len(s):.2f}")
