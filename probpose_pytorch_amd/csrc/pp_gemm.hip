@@ -1521,7 +1521,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(GemmParams p) {
 #endif
 }
 
-// pp_gemm_quad.hip: tiles 15 - 17 (four waves, one per SIMD, 128x128 / 128x96 / 96x144 wave tiles)
+// pp_gemm_quad.hip: tiles 18 - 20 (four waves, one per SIMD, 128x96 / 96x144 / 96x128 wave tiles, persistent stream;
+// 15 - 17: the per-launch forms, lab builds only)
 int gemm_quad_launch(const GemmParams &p, int cfg, dim3 grid, hipStream_t s);
 void gemm_quad_tile_shape(int cfg, int *bm, int *bn);
 
@@ -1619,7 +1620,7 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
   // (8 consumer + 4 producer waves, 3 stages), 7 = 192x384 (8 waves, 2 stages; wide-N layers such as fc1),
   // 8 = 256x256 (8 waves, 2 stages), 9 = 192x256 (8 waves, 2 stages; N = 256 layers: one column tile, A read once).  Auto: cost = rounds of co-resident workgroups x padded tile area / relative per-CU
   // throughput of the configuration.
-  PP_REQUIRE(a->tile >= 0 && a->tile <= 19 && a->tile != 11 && a->tile != 12,
+  PP_REQUIRE(a->tile >= 0 && a->tile <= 20 && a->tile != 11 && a->tile != 12,
              "pp_gemm: bad tile selector %d (11 / 12: round-2 experiments, removed)", a->tile);
   auto rounds = [&](int bm, int bn, int slots) {
     const long long tiles = (long long)cdiv(a->M, bm) * cdiv(a->N, bn) * batch;
@@ -1674,11 +1675,11 @@ extern "C" int pp_gemm(const pp_gemm_args *a, void *stream) {
     PP_REQUIRE(a->dtype == PP_BF16 && !a->rowoff && !a->out_rowmap && vec && p.lds_epilogue && batch == 1 &&
                    a->Kd % 64 == 0 && a->Kd >= 128 && (a->N & 7) == 0 &&
                    !(a->epilogue & ~(PP_EPI_BIAS | PP_EPI_GELU | PP_EPI_RELU | PP_EPI_HEADMAJOR | (1 << 30))),
-               "pp_gemm: tiles 15 - 19 (four-wave forms) serve plain bf16 -> bf16 GEMMs with bias / GELU / ReLU epilogues, "
+               "pp_gemm: tiles 15 - 20 (four-wave forms) serve plain bf16 -> bf16 GEMMs with bias / GELU / ReLU epilogues, "
                "K >= 128");
     if (cfg >= 18)
       PP_REQUIRE(a->M % bm == 0 && a->N % bn == 0 && a->Kd >= 512 && (unsigned long long)a->M * a->ldc * 2 < 0xFFFFFFF0ull,
-                 "pp_gemm: tiles 18 / 19 (four-wave stream) need M %% %d == 0, N %% %d == 0, K >= 512 and C below 4 GiB", bm, bn);
+                 "pp_gemm: tiles 18 - 20 (four-wave stream) need M %% %d == 0, N %% %d == 0, K >= 512 and C below 4 GiB", bm, bn);
     return gemm_quad_launch(p, cfg, grid, s);
   }
   if (cfg == 14) {

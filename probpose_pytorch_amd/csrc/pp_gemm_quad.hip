@@ -65,6 +65,10 @@ struct QuadPiece {
   unsigned long long sbase;      // uniform
   unsigned lds;                  // uniform LDS byte offset of the piece
 };
+// one piece, unconditionally (the stream form: a K-tile always has a successor to request)
+__device__ __forceinline__ void glds_piece(const QuadPiece &a) {
+  asm volatile(PP_QB_PIECE("%0", "%1", "%2") : : "s"(a.lds), "v"(a.voff), "s"(a.sbase) : "memory");
+}
 template <int BIT>
 __device__ __forceinline__ void glds_burst(int mask, const QuadPiece &a) {
   asm volatile(PP_QB_OPEN(%c1) PP_QB_PIECE("%2", "%3", "%4") PP_QB_CLOSE
@@ -91,16 +95,24 @@ __device__ __forceinline__ void glds_burst(int mask, const QuadPiece &a, const Q
                  "v"(b.voff), "s"(b.sbase), "s"(c.lds), "v"(c.voff), "s"(c.sbase), "s"(d.lds), "v"(d.voff), "s"(d.sbase)
                : "memory", "scc");
 }
-// s_waitcnt vmcnt(rem >= 2 ? N2 : rem == 1 ? N1 : 0), lgkmcnt(0), s_barrier: the top of a K-tile (branches inside, as above)
+// Top of a K-tile: s_waitcnt vmcnt(rem >= 2 ? N2 : rem == 1 ? N1 : 0) -- the choice between immediates is a branch inside
+// the asm statement, as above -- then lgkmcnt(0) and the barrier as BUILTINS: hipcc has to see that the fragment reads of
+// the previous iteration are complete.  With the lgkmcnt wait hidden in asm its wait-count pass assumed them still in
+// flight at the loop header and guarded this iteration's MFMAs with counted lgkmcnt waits that in fact waited for the
+// reads just issued for the NEXT K-tile: ~500 of 1370 cycles per K-tile (measured: the loop ran as long with no DMA piece).
 template <int N2, int N1>
 __device__ __forceinline__ void wait_tiles_barrier(int rem) {
   asm volatile("s_cmp_lt_i32 %0, 2\n\ts_cbranch_scc1 .Lw1_%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lwd_%=\n"
                ".Lw1_%=:\n\ts_cmp_lt_i32 %0, 1\n\ts_cbranch_scc1 .Lw0_%=\n\ts_waitcnt vmcnt(%2)\n\ts_branch .Lwd_%=\n"
                ".Lw0_%=:\n\ts_waitcnt vmcnt(0)\n"
-               ".Lwd_%=:\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier"
+               ".Lwd_%=:"
                :
                : "s"(__builtin_amdgcn_readfirstlane(rem)), "n"(N2), "n"(N1)
                : "memory", "scc");
+  __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) only
+#ifndef PP_QUAD_ABL_NOBAR      /* lab: no barrier (racy) */
+  __builtin_amdgcn_s_barrier();
+#endif
 }
 __device__ __forceinline__ unsigned long long uniform64(const void *p) {
   const unsigned long long v = (unsigned long long)p;
@@ -108,6 +120,7 @@ __device__ __forceinline__ unsigned long long uniform64(const void *p) {
          (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
 
+#ifdef PP_GEMM_LAB   // the per-launch form: lab builds only (tools/build_lab.sh), where its ablation switches live
 template <int TM, int TN, int ACT>   // ACT: 0 none, 1 GELU, 2 ReLU
 __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
     [&]<int... MI>(std::integer_sequence<int, MI...>) {
       ([&] {
         constexpr int m = MI, i = m / TN, j = m % TN;
+#ifndef PP_QUAD_ABL_NOREAD   /* lab: no fragment prefetch (the next K-tile reuses stale fragments; results wrong) */
         if constexpr (j == 0) {
           na[i] = *reinterpret_cast<const u32x4 *>(sb + offA + i * 16 * RB);
           [&]<int... J>(std::integer_sequence<int, J...>) {
@@ -241,9 +255,14 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
             }(), ...);
           }(std::make_integer_sequence<int, TN>{});
         }
+#endif
         [&]<int... B>(std::integer_sequence<int, B...>) {
           ([&] {
+#ifndef PP_QUAD_ABL_NOPIECE   /* lab: no DMA statements at all in the K-loop (not even skipped ones) */
             if constexpr ((B * TM * TN) / 8 == m) stage_slot(std::integral_constant<int, B>{}, on);
+#else
+            (void)B;
+#endif
           }(), ...);
         }(std::make_integer_sequence<int, 8>{});
         mfma_bf16(acc[i][j], cb[j], ca[i]);
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   }
   u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
   wait_vmcnt<3 * PMAX>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
   read_frags(0, fa0, fb0);
 #ifdef PP_GEMM_TIMELINE
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
   rt_loop1 = __builtin_amdgcn_s_memrealtime();
   ct_loop1 = __builtin_amdgcn_s_memtime();
 #endif
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();     // every wave is past its last fragment read: the ring is dead
 
   // ---- epilogue: bias + activation, the bf16 tile through LDS (row stride CS), then whole rows in 16-byte chunks.
@@ -362,27 +381,28 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_kernel(GemmParams p) {
 #endif
 }
 
+#endif  // PP_GEMM_LAB
+
 // ---------------------------------------------------------------------------------------------------------
 // STREAM form of the quad kernel (tiles 18 / 19): one workgroup per CU walks its tiles as ONE stream of K-tiles.
 //
 // The per-launch form above spends a third of a workgroup's life outside its K-loop (timeline, ViT-B qkv, 192 x 288
 // tiles: 2.9 us fill + 17.4 us K-loop + 5.3 us epilogue + 0.3 us until the next workgroup starts), and with one wave
 // per SIMD nothing runs beside it.  Here the ring never drains: the last four K-tile slots of a tile already request
-// the next tile's first four K-tiles, and the finished tile leaves without a workgroup barrier and without waiting for
-// memory: every wave turns its own 16-row blocks into bf16 (bias from the wave's own LDS slot, activation), turns each
-// block through a wave-private LDS scratch (a wave's LDS operations execute in order: no wait between its write and its
-// read-back) into whole 16-byte row chunks, and fires the stores; the next tile's K-loop starts right behind them.
-// (Stored straight from the accumulator layout -- 8 bytes per lane, 32-byte row segments -- the 54 stores of a tile cost
-// ~240 cycles each: measured, 6.5 us per tile.)
+// the next tile's first four K-tiles, and the finished tile leaves without LDS, without a workgroup barrier and without
+// waiting for memory: at the end of its K-loop every wave turns its accumulators into packed bf16 16-byte chunks held in
+// registers (bias from the wave's own LDS slot, activation, a lane-pair exchange), and those leave from the NEXT tile's
+// first 12 K-tile iterations, two or three stores per iteration between the MFMAs.
 //
-// vmcnt is ONE in-order counter for LDS-DMA pieces and stores, so the counted waits of a tile's first iterations are
-//   2 * PMAX + (the stores / the one bias piece issued since the awaited K-tile's last piece),
-// known at compile time except whether a previous tile's stores exist (`hp`).  Every wave issues exactly the same
-// number of VMEM operations per iteration and per epilogue (chunks outside the block get an out-of-range offset, which
-// the buffer descriptor drops, instead of a branch).
+// vmcnt is ONE in-order counter for LDS-DMA pieces and stores, so the counted wait of iteration t is
+//   2 * PMAX + (the stores and the one bias piece that iterations t - 2 and t - 1 issued),
+// a compile-time constant: the first 14 iterations of a tile are unrolled (their stores name registers), the rest is a
+// loop with no branch but its back edge.  Every wave issues exactly the same VMEM operations per iteration; before a
+// workgroup's first tile the chunk stores carry an out-of-range offset, which the buffer descriptor drops.
 // Requires M % BM == 0, N % BN == 0 (per-lane staging offsets are tile-independent), K >= 512, C below 4 GiB.
 // ---------------------------------------------------------------------------------------------------------
 typedef int i32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void mfma_bf16_zero(f32x4 &c, const u32x4 &w, const u32x4 &a) {   // first K-tile of a tile
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(a));
@@ -394,20 +414,30 @@ __device__ __forceinline__ void store16(const u32x4 &v, unsigned voff, const i32
   // registers late: the next instruction must not overwrite them)
   asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(srd) : "memory");
 }
-// s_waitcnt vmcnt(sel ? N1 : N0), lgkmcnt(0), s_barrier
+// s_waitcnt vmcnt(sel ? N1 : N0), then lgkmcnt(0) and the barrier as builtins (see wait_tiles_barrier)
 template <int N1, int N0>
 __device__ __forceinline__ void wait_sel_barrier(int sel) {
   static_assert(N1 <= 63 && N0 <= 63, "vmcnt is a 6-bit counter");
-  asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc0 .Lw0_%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lwd_%=\n"
-               ".Lw0_%=:\n\ts_waitcnt vmcnt(%2)\n"
-               ".Lwd_%=:\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier"
-               :
-               : "s"(__builtin_amdgcn_readfirstlane(sel)), "n"(N1), "n"(N0)
-               : "memory", "scc");
+  if constexpr (N1 == N0) {
+    wait_vmcnt<N1>();
+  } else {
+    asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc0 .Lw0_%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lwd_%=\n"
+                 ".Lw0_%=:\n\ts_waitcnt vmcnt(%2)\n"
+                 ".Lwd_%=:"
+                 :
+                 : "s"(__builtin_amdgcn_readfirstlane(sel)), "n"(N1), "n"(N0)
+                 : "memory", "scc");
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+}
+// 8 bytes per lane (the odd last column tile of a 16-row block)
+__device__ __forceinline__ void store8(const u32x2 &v, unsigned voff, const i32x4s &srd) {
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(srd) : "memory");
 }
 
 constexpr int quad_stream_lds_bytes(int TM, int TN) {
-  return 4 * (32 * TM + 32 * TN) * 64 + 2 * 4096 + 4 * 16 * (32 * TN + 16);
+  return 4 * (32 * TM + 32 * TN) * 64 + 2 * 4096;
 }
 
 template <int TM, int TN, int ACT>   // ACT: 0 none, 1 GELU, 2 ReLU
@@ -421,14 +451,13 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   constexpr int PTA = BM / 16, PT = (BM + BN) / 16, PMAX = (PT + 3) / 4, PREM = PT % 4, KA = PTA / 4;
   constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB, RING = STAGES * STAGE_BYTES;
   constexpr int BIAS_OFF = RING;                        // two tile parities x four waves x 1 KiB
-  constexpr int SCR_OFF = BIAS_OFF + 2 * 4096;          // per wave: one 16-row block of its tile, row stride RS
-  constexpr int RS = 32 * TN + 16, CPRW = 2 * TN;       // 16-byte chunks per block row
-  constexpr int NIT = (16 * CPRW + 63) / 64;            // store instructions per block
+  constexpr int NPAIR = TN / 2, NIT = NPAIR + (TN & 1);  // store instructions per 16-row block: column-tile pairs (+ an odd one)
   constexpr int ST = TM * NIT;                          // ... per tile and wave
+  constexpr int NSI = 12;                               // the K-tiles of the NEXT tile that carry them (2 - 3 each)
   constexpr int SLOT0 = 8 - PMAX;                       // pieces sit in slots SLOT0 .. 7
   constexpr int P2 = 2 * PMAX;
   static_assert(PTA % 4 == 0 && PMAX <= 8 && PMAX - 2 >= KA, "piece layout");
-  static_assert(P2 + ST <= 63, "vmcnt is a 6-bit counter");
+  static_assert(P2 + 2 * ((ST + NSI - 1) / NSI) + 1 <= 63, "vmcnt is a 6-bit counter");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
@@ -483,9 +512,9 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
     constexpr int k = decltype(kc)::value;
     return QuadPiece{off[k], k < KA ? st_A : st_W, st_lds + (k == PMAX - 1 ? last_k : k) * 4096};
   };
-  auto stage_slot = [&](auto bc, int mask) __attribute__((always_inline)) {   // slot B carries piece B - SLOT0 of every wave
+  auto stage_slot = [&](auto bc) __attribute__((always_inline)) {   // slot B carries piece B - SLOT0 of every wave
     constexpr int B = decltype(bc)::value;
-    if constexpr (B >= SLOT0) glds_burst<B>(mask, piece(std::integral_constant<int, B - SLOT0>{}));
+    if constexpr (B >= SLOT0) glds_piece(piece(std::integral_constant<int, B - SLOT0>{}));
   };
   auto tile_base = [&](int tm, int tn, unsigned long long &bA, unsigned long long &bW) __attribute__((always_inline)) {
     bA = uniform64(p.A + (size_t)tm * BM * p.lda * 2);
@@ -513,11 +542,32 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
 
   // One K-tile of the stream (straight-line code).  ZC: first K-tile of a tile (the MFMAs start the accumulators from 0).
   // BP: the next tile's bias piece leaves first.
-  auto iter = [&](u32x4 (&ca)[TM], u32x4 (&cb)[TN], u32x4 (&na)[TM], u32x4 (&nb)[TN], int rbuf, int on, auto zc_c, auto bp_c,
-                  const QuadPiece &bpiece) __attribute__((always_inline)) {
+  // TI >= 0: chunk stores [TI ST / NSI, (TI + 1) ST / NSI) of the PREVIOUS tile leave between the MFMAs, all before slot 7.
+  u32x4 pk16[TM][NPAIR > 0 ? NPAIR : 1];
+  u32x2 pk8[TM];
+  unsigned cp[NIT];           // byte offset of (row frow of block 0, the lane's columns in pair / odd tile jp) of the packed tile
+  unsigned block_step = 0;    // bytes between 16-row blocks
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    pk8[i] = u32x2{0u, 0u};
+#pragma unroll
+    for (int jp = 0; jp < NPAIR; ++jp) pk16[i][jp] = u32x4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int jp = 0; jp < NIT; ++jp) cp[jp] = 0xFFFFFFF0u;      // before the first tile: out of range, the descriptor drops them
+  auto chunk_store = [&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, i = q / NIT, jp = q % NIT;
+    // saturating: an out-of-range offset stays out of range
+    const unsigned o = __builtin_elementwise_add_sat(cp[jp], (unsigned)i * block_step);
+    if constexpr (jp < NPAIR) store16(pk16[i][jp], o, c_srd);
+    else store8(pk8[i], o, c_srd);
+  };
+  auto iter = [&](u32x4 (&ca)[TM], u32x4 (&cb)[TN], u32x4 (&na)[TM], u32x4 (&nb)[TN], int rbuf, auto zc_c, auto bp_c,
+                  const QuadPiece &bpiece, auto ti_c) __attribute__((always_inline)) {
     constexpr bool ZC = decltype(zc_c)::value, BP = decltype(bp_c)::value;
+    constexpr int TI = decltype(ti_c)::value;
     const char *sb = smem + rbuf * STAGE_BYTES;
-    if constexpr (BP) glds_burst<0>(1, bpiece);
+    if constexpr (BP) glds_piece(bpiece);
     [&]<int... MI>(std::integer_sequence<int, MI...>) {
       ([&] {
         constexpr int m = MI, i = m / TN, j = m % TN;
@@ -531,9 +581,15 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
         }
         [&]<int... B>(std::integer_sequence<int, B...>) {
           ([&] {
-            if constexpr ((B * TM * TN) / 8 == m) stage_slot(std::integral_constant<int, B>{}, on);
+            if constexpr ((B * TM * TN) / 8 == m) stage_slot(std::integral_constant<int, B>{});
           }(), ...);
         }(std::make_integer_sequence<int, 8>{});
+        if constexpr (TI >= 0 && TI < NSI) {
+          constexpr int Q0 = (TI * ST) / NSI, Q1 = ((TI + 1) * ST) / NSI, NS = Q1 - Q0;
+          constexpr int LIMIT = (7 * TM * TN) / 8, STEP = NS > 0 ? (LIMIT - 2) / NS : 1;
+          if constexpr (NS > 0 && m >= 2 && (m - 2) % STEP == 0 && (m - 2) / STEP < NS)
+            chunk_store(std::integral_constant<int, Q0 + (m - 2) / STEP>{});
+        }
         if constexpr (ZC) mfma_bf16_zero(acc[i][j], cb[j], ca[i]);
         else mfma_bf16(acc[i][j], cb[j], ca[i]);
       }(), ...);
@@ -548,19 +604,19 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   unsigned long long curA, curW, nxtA = 0, nxtW = 0;
   tile_base(tm, tn, curA, curW);
   int par = 0;
-  glds_burst<0>(1, bias_piece(tn, par));
+  glds_piece(bias_piece(tn, par));
 #pragma unroll
   for (int s_ = 0; s_ < STAGES; ++s_) {
     st_lds = __builtin_amdgcn_readfirstlane(lds0 + s_ * STAGE_BYTES + wave * 1024);
     st_A = curA + (unsigned)(s_ * RB);
     st_W = curW + (unsigned)(s_ * RB);
     [&]<int... B>(std::integer_sequence<int, B...>) {
-      (stage_slot(std::integral_constant<int, B>{}, 0xFF), ...);
+      (stage_slot(std::integral_constant<int, B>{}), ...);
     }(std::make_integer_sequence<int, 8>{});
   }
   u32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
   wait_vmcnt<3 * PMAX>();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int j = 0; j < TN; ++j) fb0[j] = *reinterpret_cast<const u32x4 *>(smem + offB + j * 16 * RB);
@@ -571,7 +627,12 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   ct_loop0 = __builtin_amdgcn_s_memtime();
 #endif
 
-  int hp = 0, b = 0;          // hp: a previous tile's stores are in the queue; b: ring buffer of the stream's current K-tile
+  int b = 0;                  // ring buffer of the stream's current K-tile
+  // VMEM operations of iteration t of a tile besides its PMAX pieces: the previous tile's chunk stores, the bias piece
+  auto extras = [](int t) constexpr {
+    if (t < 0) return 0;
+    return (t < NSI ? ((t + 1) * ST) / NSI - (t * ST) / NSI : 0) + (t == 1 ? 1 : 0);
+  };
   for (;;) {
     const int m0 = tm * BM, n0 = tn * BN;
     // the tile after this one (its first four K-tiles are requested by this tile's last four iterations)
@@ -581,123 +642,122 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
     if (has_next) decode(nvb, ntm, ntn);
     tile_base(ntm, ntn, nxtA, nxtW);
     const QuadPiece nbias = bias_piece(ntn, par ^ 1);
-    // K-tile t of this tile requests K-tile t + 4: of this tile, or K-tile t + 4 - nkt of the next one
+    // K-tile t of this tile requests K-tile t + 4: of this tile, or K-tile t + 4 - nkt of the next one.  No predicate: at
+    // the end of the stream (no next tile: nxtA / nxtW are this tile's) the last four K-tiles re-request K-tiles 0 .. 3
+    // into ring buffers nobody reads any more; the kernel waits for them before it ends.  (A skipped piece is a taken
+    // branch, and taken branches are what a one-wave-per-SIMD loop cannot afford: see DESIGN 4.1.)
     auto stage_begin = [&](int t) __attribute__((always_inline)) {
       const int kt = t + 4, wrap = kt >= nkt ? 1 : 0;
       const int k2 = wrap ? kt - nkt : kt;
       st_lds = __builtin_amdgcn_readfirstlane(lds0 + b * STAGE_BYTES + wave * 1024);
       st_A = (wrap ? nxtA : curA) + (unsigned)(k2 * RB);
       st_W = (wrap ? nxtW : curW) + (unsigned)(k2 * RB);
-      return (wrap && !has_next) ? 0 : 0xFF;
     };
-    // -- iterations 0 .. 5.  What is younger than the awaited K-tile's last piece: 0 - 2: two K-tiles of pieces and, behind a
-    // previous tile, its ST stores; 3, 4: two K-tiles and the bias piece of iteration 2; from 5 on: two K-tiles.
-    wait_sel_barrier<P2 + ST, P2>(hp);
-    iter(fa0, fb0, fa1, fb1, (b + 1) & 3, stage_begin(0), T, F, nbias);
-    b = (b + 1) & 3;
-    wait_sel_barrier<P2 + ST, P2>(hp);
-    iter(fa1, fb1, fa0, fb0, (b + 1) & 3, stage_begin(1), F, F, nbias);
-    b = (b + 1) & 3;
-    wait_sel_barrier<P2 + ST, P2>(hp);
-    iter(fa0, fb0, fa1, fb1, (b + 1) & 3, stage_begin(2), F, T, nbias);
-    b = (b + 1) & 3;
-    wait_sel_barrier<P2 + 1, P2 + 1>(1);
-    iter(fa1, fb1, fa0, fb0, (b + 1) & 3, stage_begin(3), F, F, nbias);
-    b = (b + 1) & 3;
-    wait_sel_barrier<P2 + 1, P2 + 1>(1);
-    iter(fa0, fb0, fa1, fb1, (b + 1) & 3, stage_begin(4), F, F, nbias);
-    b = (b + 1) & 3;
-    wait_sel_barrier<P2, P2>(1);
-    iter(fa1, fb1, fa0, fb0, (b + 1) & 3, stage_begin(5), F, F, nbias);
-    b = (b + 1) & 3;
-    // -- steady loop: exactly the per-launch form's; at the end of the stream the last K-tiles request nothing
-    for (int t = 6; t < nkt; t += 2) {
-      wait_tiles_barrier<P2, PMAX>(has_next ? 2 : nkt - 2 - t);
-      iter(fa0, fb0, fa1, fb1, (b + 1) & 3, stage_begin(t), F, F, nbias);
+    // -- iterations 0 .. NSI + 1, unrolled: each carries its share of the previous tile's chunk stores (compile-time
+    // registers) and waits for 2 PMAX + what the two iterations before it issued besides their pieces
+    [&]<int... TI>(std::integer_sequence<int, TI...>) {
+      ([&] {
+        wait_sel_barrier<P2 + extras(TI - 2) + extras(TI - 1), P2 + extras(TI - 2) + extras(TI - 1)>(1);
+        stage_begin(TI);
+        if constexpr ((TI & 1) == 0)
+          iter(fa0, fb0, fa1, fb1, (b + 1) & 3, std::bool_constant<TI == 0>{}, std::bool_constant<TI == 1>{}, nbias,
+               std::integral_constant<int, TI>{});
+        else
+          iter(fa1, fb1, fa0, fb0, (b + 1) & 3, std::bool_constant<TI == 0>{}, std::bool_constant<TI == 1>{}, nbias,
+               std::integral_constant<int, TI>{});
+        b = (b + 1) & 3;
+      }(), ...);
+    }(std::make_integer_sequence<int, NSI + 2>{});
+    // -- steady loop: no branch but its own back edge
+    for (int t = NSI + 2; t < nkt; t += 2) {
+      wait_sel_barrier<P2, P2>(1);
+      stage_begin(t);
+      iter(fa0, fb0, fa1, fb1, (b + 1) & 3, F, F, nbias, std::integral_constant<int, -1>{});
       b = (b + 1) & 3;
-      wait_tiles_barrier<P2, PMAX>(has_next ? 2 : nkt - 3 - t);
-      iter(fa1, fb1, fa0, fb0, (b + 1) & 3, stage_begin(t + 1), F, F, nbias);
+      wait_sel_barrier<P2, P2>(1);
+      stage_begin(t + 1);
+      iter(fa1, fb1, fa0, fb0, (b + 1) & 3, F, F, nbias, std::integral_constant<int, -1>{});
       b = (b + 1) & 3;
       asm volatile("s_nop 11" ::: "memory");      // MFMA -> v_accvgpr_read hazard behind the loop (see gemm_quad_kernel)
     }
 #ifdef PP_GEMM_TIMELINE
     const unsigned long long cc0 = __builtin_amdgcn_s_memtime();
 #endif
-    // -- the finished tile, per wave, no barrier: 16-row block i -> bias, activation, bf16 -> the wave's LDS scratch in
-    // accumulator layout -> read back as 16-byte row chunks -> NIT stores per block (always NIT: see the head comment)
+    // -- the finished tile, per wave, no LDS, no barrier: accumulators -> packed 16-byte chunks in registers; they leave from
+    // the next tile's first NSI K-tiles, two or three per K-tile, so that the chip's 256 CUs -- which all finish their tiles
+    // within the same microsecond -- never write in a burst (stored at once, the 28 MB of a qkv round filled the write path
+    // and every store waited for it: 4.9 us per tile, measured).
+    // A lane (frow, fq) owns 4 consecutive columns of row frow in every 16 x 16 MFMA tile.  Two v_permlane16_swap_b32 per
+    // pair of column tiles (j, j + 1) hand every lane 8 consecutive columns instead: even fq gets columns 4 fq .. 4 fq + 7 of
+    // tile j (its own 4 + those of lane fq + 1), odd fq columns 4 (fq - 1) .. + 7 of tile j + 1: one 16-byte store per lane,
+    // 64 contiguous bytes per row and store.
     {
       const float *lbias = reinterpret_cast<const float *>(smem + BIAS_OFF + par * 4096 + wave * 1024);
-      char *scr = smem + SCR_OFF + wave * (16 * RS);
       const bool has_bias = (epi & PP_EPI_BIAS) != 0, headmajor = (epi & PP_EPI_HEADMAJOR) != 0;
       float4 b4[TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         // this wave's own piece, issued a whole tile ago and older than everything a later counted wait retired
-        if (has_bias) b4[j] = *reinterpret_cast<const float4 *>(lbias + min(j * 16 + fq * 4, p.N - 4 - (n0 + wn * 16 * TN)));
+        if (has_bias) b4[j] = *reinterpret_cast<const float4 *>(lbias + j * 16 + fq * 4);
       }
-      // chunk c = lane + 64 it of a block: row c / CPRW, 8 columns from (c % CPRW) * 8; its byte offset in C without the
-      // block's row base (rows 16 i of the wave tile)
-      unsigned coff[NIT];
-      int crow[NIT], ccol[NIT];
+      const int ld_out = headmajor ? p.hm_HW : p.ldc;
+      const unsigned row0 = (unsigned)(m0 + wm * 16 * TM + frow) * (unsigned)ld_out * 2u;
+      block_step = 16u * (unsigned)ld_out * 2u;
+      auto col_off = [&](int n) -> unsigned {     // byte offset of column n inside a row (head-major: of its head's slab)
+        if (!headmajor) return (unsigned)n * 2u;
+        const int hh = n / p.hm_HW, d = n - hh * p.hm_HW;   // [3][heads][M][head_dim]: 8 columns never straddle a head
+        return (unsigned)(((size_t)hh * p.M * p.hm_HW + d) * 2);
+      };
+      const int lane_col = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int c = lane + 64 * it;
-        crow[it] = c / CPRW;
-        ccol[it] = c - crow[it] * CPRW;
-        const int r = m0 + wm * 16 * TM + crow[it], n = n0 + wn * 16 * TN + ccol[it] * 8;
-        if (c >= 16 * CPRW) {
-          coff[it] = 0xFFFFFFF0u;                 // dropped by the descriptor's range check (and stays there: see below)
-          crow[it] = 0; ccol[it] = 0;
-        } else if (headmajor) {                   // [3][heads][M][head_dim]: a chunk never straddles a head (head_dim % 8 == 0)
-          const int hh = n / p.hm_HW, d = n - hh * p.hm_HW;
-          coff[it] = (unsigned)((((size_t)hh * p.M + r) * p.hm_HW + d) * 2);
-        } else {
-          coff[it] = (unsigned)(((size_t)r * p.ldc + n) * 2);
-        }
-      }
-      const unsigned block_step = 16u * (unsigned)(headmajor ? p.hm_HW : p.ldc) * 2u;
+      for (int jp = 0; jp < NPAIR; ++jp) cp[jp] = row0 + col_off(n0 + wn * 16 * TN + jp * 32 + lane_col);
+      if constexpr (TN & 1) cp[NPAIR] = row0 + col_off(n0 + wn * 16 * TN + (TN - 1) * 16 + fq * 4);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        // a whole 16-row block at once: 4 TN values per lane, the activation over all of them side by side
+        float v[4 * TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          float v[4] = {acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w};
-          if constexpr (ACT == 1) gelu4<bf16_t>(v);
-          if constexpr (ACT == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          uint2 pk;
-          pk.x = pack_bf16x2(v[0], v[1]);
-          pk.y = pack_bf16x2(v[2], v[3]);
-          *reinterpret_cast<uint2 *>(scr + frow * RS + (j * 16 + fq * 4) * 2) = pk;
+          v[4 * j] = acc[i][j][0] + b4[j].x;
+          v[4 * j + 1] = acc[i][j][1] + b4[j].y;
+          v[4 * j + 2] = acc[i][j][2] + b4[j].z;
+          v[4 * j + 3] = acc[i][j][3] + b4[j].w;
         }
-        // the block must have landed before it is read back (measured: without the wait a read-back returns stale bytes
-        // for some lanes, a wave's ds_write / ds_read pair is NOT ordered by the LDS queue alone), and hipcc must not move
-        // the reads above the writes either (they use different types)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (ACT == 1) gelu_fast_n<4 * TN>(v);
+        if constexpr (ACT == 2) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-          const u32x4 v = *reinterpret_cast<const u32x4 *>(scr + crow[it] * RS + ccol[it] * 16);
-          // an out-of-block lane keeps its out-of-range offset: no wrap-around into the buffer (0xFFFFFFF0 + i * step
-          // would come back in range)
-          store16(v, 64 * it + lane < 16 * CPRW ? coff[it] + i * block_step : 0xFFFFFFF0u, c_srd);
+          for (int e = 0; e < 4 * TN; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        asm volatile("" ::: "memory");
+        unsigned w[2 * TN];
+#pragma unroll
+        for (int e = 0; e < 2 * TN; ++e) w[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) {          // tiles 2 jp (x) and 2 jp + 1 (y): dwords w[4 jp .. 4 jp + 3]
+          const auto r0 = __builtin_amdgcn_permlane16_swap(w[4 * jp], w[4 * jp + 2], false, false);
+          const auto r1 = __builtin_amdgcn_permlane16_swap(w[4 * jp + 1], w[4 * jp + 3], false, false);
+          pk16[i][jp] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+        if constexpr (TN & 1) pk8[i] = u32x2{w[2 * TN - 2], w[2 * TN - 1]};
       }
     }
 #ifdef PP_GEMM_TIMELINE
     ct_conv += __builtin_amdgcn_s_memtime() - cc0;
 #endif
-    hp = 1;
     if (!has_next) break;
     vb = nvb; tm = ntm; tn = ntn; curA = nxtA; curW = nxtW; par ^= 1;
   }
 #ifdef PP_GEMM_TIMELINE
   rt_loop1 = __builtin_amdgcn_s_memrealtime();
   ct_loop1 = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- the last tile's chunks; the stream's last (unused) K-tile requests must land before the LDS is freed
+  [&]<int... Q>(std::integer_sequence<int, Q...>) {
+    (chunk_store(std::integral_constant<int, Q>{}), ...);
+  }(std::make_integer_sequence<int, ST>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PP_GEMM_TIMELINE
   if ((p.epilogue & (1 << 30)) && lane == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
     unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(p.rowbias)) +
                             ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -709,6 +769,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
 #endif
 }
 
+#ifdef PP_GEMM_LAB
 template <int TM, int TN>
 static int quad_launch_shape(const GemmParams &p, dim3 grid, hipStream_t s) {
   constexpr int lds = quad_lds_bytes(TM, TN);
@@ -728,6 +789,8 @@ static int quad_launch_shape(const GemmParams &p, dim3 grid, hipStream_t s) {
   PP_CHECK_LAUNCH("gemm_quad_kernel");
   return 0;
 }
+
+#endif
 
 template <int TM, int TN>
 static int quad_stream_launch_shape(const GemmParams &p, dim3 grid, hipStream_t s) {
@@ -759,21 +822,24 @@ static int quad_stream_launch_shape(const GemmParams &p, dim3 grid, hipStream_t 
   return 0;
 }
 
-// tiles 15 - 19 of pp_gemm (argument checks are the caller's: pp_gemm.hip)
+// tiles 15 - 20 of pp_gemm (argument checks are the caller's: pp_gemm.hip)
 int gemm_quad_launch(const GemmParams &p, int cfg, dim3 grid, hipStream_t s) {
   switch (cfg) {
-    case 15: return quad_launch_shape<8, 8>(p, grid, s);    // 256 x 256
+#ifdef PP_GEMM_LAB
+    case 15: return quad_launch_shape<8, 8>(p, grid, s);    // 256 x 256, per launch
     case 16: return quad_launch_shape<8, 6>(p, grid, s);    // 256 x 192
     case 17: return quad_launch_shape<6, 9>(p, grid, s);    // 192 x 288
+#endif
     case 18: return quad_stream_launch_shape<8, 6>(p, grid, s);   // 256 x 192, stream
     case 19: return quad_stream_launch_shape<6, 9>(p, grid, s);   // 192 x 288, stream
-    default: return fail("gemm_quad_launch: bad tile %d", cfg);
+    case 20: return quad_stream_launch_shape<6, 8>(p, grid, s);   // 192 x 256, stream
+    default: return fail("pp_gemm: tile %d (the per-launch four-wave forms 15 - 17) exists in lab builds only", cfg);
   }
 }
 
 void gemm_quad_tile_shape(int cfg, int *bm, int *bn) {
-  *bm = (cfg == 17 || cfg == 19) ? 192 : 256;
-  *bn = cfg == 15 ? 256 : ((cfg == 16 || cfg == 18) ? 192 : 288);
+  *bm = (cfg == 17 || cfg == 19 || cfg == 20) ? 192 : 256;
+  *bn = (cfg == 15 || cfg == 20) ? 256 : ((cfg == 16 || cfg == 18) ? 192 : 288);
 }
 
 }  // namespace pp

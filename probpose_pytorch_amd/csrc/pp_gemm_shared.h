@@ -79,6 +79,38 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
   const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + (f32x2){1.0f, 1.0f};
   return x * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
 }
+// N values at once, stage by stage: N / 2 independent chains side by side.  One chain alone is a string of dependent
+// packed / transcendental instructions that hipcc pads with an s_nop per link (seen in the ISA: 591 nops in the GELU of a
+// 128 x 96 wave tile, twice the time of the arithmetic).
+template <int N>
+__device__ __forceinline__ void gelu_fast_n(float (&v)[N]) {
+  static_assert(N % 2 == 0, "pairs");
+  const f32x2 c2 = {0.001035082619637251f, 0.001035082619637251f};
+  const f32x2 c1 = {-0.10690470039844513f, -0.10690470039844513f};
+  const f32x2 c0 = {-2.300978660583496f, -2.300978660583496f};
+  f32x2 x[N / 2], t[N / 2];
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) {
+    x[k] = (f32x2){v[2 * k], v[2 * k + 1]};
+    t[k] = __builtin_elementwise_min(x[k] * x[k], (f32x2){50.0f, 50.0f});
+  }
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) t[k] = __builtin_elementwise_fma(__builtin_elementwise_fma(c2, t[k], c1), t[k], c0);
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) t[k] = x[k] * t[k];
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) t[k] = (f32x2){__builtin_amdgcn_exp2f(t[k].x), __builtin_amdgcn_exp2f(t[k].y)};
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) t[k] = t[k] + (f32x2){1.0f, 1.0f};
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) t[k] = (f32x2){__builtin_amdgcn_rcpf(t[k].x), __builtin_amdgcn_rcpf(t[k].y)};
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) {
+    const f32x2 r = x[k] * t[k];
+    v[2 * k] = r.x;
+    v[2 * k + 1] = r.y;
+  }
+}
 template <typename T>
 __device__ __forceinline__ void gelu4(float (&v)[4]) {
   if constexpr (sizeof(T) <= 2) {

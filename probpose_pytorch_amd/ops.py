@@ -56,7 +56,7 @@ def _p(t):
 # configurations on scratch outputs (HIP events, outside any graph capture) and caches the winner.
 AUTOTUNE = False
 _TUNE_CACHE: dict = {}
-_TUNE_CANDIDATES = (2, 3, 4, 5, 6, 7, 9, 10, 13, 14)
+_TUNE_CANDIDATES = (2, 3, 4, 5, 6, 7, 9, 10, 13, 14, 18, 19, 20)
 
 
 def save_tune_cache(path: str) -> None:

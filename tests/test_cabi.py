@@ -67,7 +67,7 @@ def test_gemm_argument_validation_without_gpu(built_lib):
     a = _lib.GemmArgs()
     a.A, a.W, a.C = 0x1000, 0x2000, 0x3000
     a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc, a.batch, a.dtype = 192, 256, 256, 256, 256, 256, 1, _lib.PP_BF16
-    for tile in (11, 12, 20, -1):
+    for tile in (11, 12, 21, -1):
         a.tile = tile
         assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tile" in built_lib.pp_last_error()
     a.tile, a.epilogue = 9, _lib.EPI_FUSE_FINAL | _lib.EPI_RELU
