@@ -73,7 +73,7 @@ def pmc_traffic():
     n = b = 0
     dec = None
     for name, v in k.items():
-        if "gemm_kernel" in name or "gemm_persist_kernel" in name or "gemm_duo_kernel" in name:
+        if any(t in name for t in ("gemm_kernel", "gemm_persist_kernel", "gemm_duo_kernel", "gemm_quad_stream_kernel")):
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
         if "pp::decode_" in name and "pass_kernel" not in name and "argmax" not in name:
@@ -494,7 +494,7 @@ def main():
                        "gflop_per_crop": round(flops_per_crop(cfg) / 1e9, 2)},
             "decode_ms": round(d_t * 1e3, 4),
             "model_tflops": round(flops_per_crop(cfg) * crops_per_s / world / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (tile forms 2-10) / pp::gemm_persist_kernel (13) / pp::gemm_duo_kernel (14), whichever the tuner picked per shape", "achieved": round(achieved, 2), "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "pp::gemm_kernel (tile forms 2-10) / pp::gemm_persist_kernel (13) / pp::gemm_duo_kernel (14) / pp::gemm_quad_stream_kernel (18-20), whichever the tuner picked per shape", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": g_traffic,
                          "traffic_source": traffic_src, "launches_per_step": g_n, "avg_launch_us": round(g_t / max(g_n, 1) * 1e6, 2),
                          "flop_per_launch": round(g_flops / max(g_n, 1), 0)},

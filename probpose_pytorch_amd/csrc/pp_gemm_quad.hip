@@ -1,20 +1,25 @@
-// "Quad" GEMM form for gfx950: C[M,N] = act(A[M,K] W[N,K]^T + bias), bf16 in / bf16 out, fp32 accumulate.
+// "Quad" GEMM forms for gfx950 (pp_gemm tiles 18 - 20): C[M,N] = act(A[M,K] W[N,K]^T + bias), bf16 in / bf16 out, fp32
+// accumulate.  The qkv and fc1 layers of the ViT blocks: the shapes on which the vendor library led the 8-wave forms.
 //
-// FOUR waves per workgroup (2 x 2), ONE wave per SIMD, each wave owning a (16 TM) x (16 TN) output tile in up to 256
-// accumulator registers (128 x 128, 128 x 96, 96 x 144): the wave-tile shapes of the vendor's macro tiles on the
-// wide-N ViT layers (profiles/r03_gemm_vs_vendor.txt).  Against the 8-wave forms of pp_gemm.hip (96 x 48 wave tiles)
-// a K-step reads half the LDS bytes per flop: the K-loop of those forms is power-limited, and LDS read
-// bytes are one of the things that set the clock the chip holds under an MFMA-dense loop.
+// FOUR waves per workgroup (2 x 2), ONE wave per SIMD, each wave owning a (16 TM) x (16 TN) output tile in 192 - 216
+// accumulator registers (128 x 96, 96 x 144, 96 x 128): the wave-tile shapes of the vendor's macro tiles
+// (profiles/r03_gemm_vs_vendor.txt).  Against the 8-wave forms of pp_gemm.hip (96 x 48 wave tiles) a K-step reads half
+// the LDS bytes per flop.
 //
-// With one wave per SIMD nothing hides a wave's own LDS latency, so the loop is pipelined in registers: while the
-// MFMAs of K-tile t run from fragment set X, the fragments of K-tile t+1 are read into set Y (two ds_read_b128 per
-// group of TN MFMAs) and the LDS-DMA pieces of K-tile t+4 are issued into the ring buffer K-tile t has just left.
-// K-tiles are 32 deep (64-byte rows, the 4-chunk swizzle of gemm_duo_kernel), FOUR ring buffers of (BM + BN) x 64 B:
-// a K-tile is requested three iterations before its fragments are read.  One counted vmcnt wait + one barrier per
-// K-tile; no compiler-visible global access before the epilogue (bias arrives by LDS-DMA), so hipcc has no reason to
-// drain vmcnt inside the loop.  The epilogue stages the whole bf16 C tile through the dead ring and stores whole rows.
+// With one wave per SIMD nothing hides a wave's own latencies, so (1) the loop is pipelined in registers: while the
+// MFMAs of K-tile t run from fragment set X, the fragments of K-tile t + 1 are read into set Y (two ds_read_b128 per row
+// of MFMAs) and the LDS-DMA pieces of K-tile t + 4 go into the ring buffer K-tile t has just left (K-tiles 32 deep,
+// 64-byte rows, the 4-chunk swizzle of gemm_duo_kernel, FOUR ring buffers of (BM + BN) x 64 B: a K-tile is requested
+// three iterations before its fragments are read); (2) the MFMAs are inline asm with the accumulator tied in the AGPRs
+// -- hipcc's allocator otherwise shuffles a 200-register accumulator through v_accvgpr_mov inside the loop -- which
+// makes every MFMA hazard the author's business (see the s_nop at the loop ends); (3) the K-loop has NO branch but
+// its back edge: a taken branch costs a lone wave ~26 cycles of issue, measured, so there is no predicate on a DMA
+// piece and no choice between wait immediates at run time; (4) the kernel is a persistent stream (below).
+// What the lab measurements of the per-launch form say about a K-tile of the 192 x 288 tile (54 MFMAs = 864 cycles per
+// wave): 1 361 cycles as built; 8 DMA pieces cost 31 cycles each, the fragment reads and the barrier 75, loop control
+// and waits the rest (profiles/r03_gemm_quad_experiments.txt).
 //
-// Plain layers only (no gather, no row map, no residual, no fp8): qkv and fc1 -- the shapes on which the vendor led.
+// The per-launch form (tiles 15 - 17) is kept for lab builds (tools/build_lab.sh), where its ablation switches live.
 #include <algorithm>
 #include <type_traits>
 #include <utility>
@@ -50,7 +55,8 @@ __device__ __forceinline__ void mfma_bf16(f32x4 &c, const u32x4 &w, const u32x4 
 // K-loop makes hipcc's allocator split the accumulators' live ranges (hundreds of v_accvgpr moves and scratch spills per
 // K-tile; seen in the ISA).  M0 is written without save / restore: nothing else in this translation unit uses it.
 #ifndef PP_QUAD_BURST
-#define PP_QUAD_BURST 1     /* 0: every wave one piece per slot; 1: staggered bursts, skipped by a branch; 2: by EXEC = 0 */
+#define PP_QUAD_BURST 0     /* lab (per-launch form): 0: every wave one piece per slot (2 722 cycles per two K-tiles of the
+                               192 x 288 tile); 1: staggered bursts skipped by a branch (2 841); 2: skipped by EXEC = 0 (4 575) */
 #endif
 #if PP_QUAD_BURST == 2
 #define PP_QB_OPEN(BIT) "s_bitcmp1_b32 %0, " #BIT "\n\ts_cselect_b64 exec, -1, 0\n\t"
@@ -713,6 +719,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
 #pragma unroll
       for (int jp = 0; jp < NPAIR; ++jp) cp[jp] = row0 + col_off(n0 + wn * 16 * TN + jp * 32 + lane_col);
       if constexpr (TN & 1) cp[NPAIR] = row0 + col_off(n0 + wn * 16 * TN + (TN - 1) * 16 + fq * 4);
+      auto blocks = [&](auto now_c) __attribute__((always_inline)) {
+      constexpr bool NOW = decltype(now_c)::value;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         // a whole 16-row block at once: 4 TN values per lane, the activation over all of them side by side
@@ -739,7 +747,25 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
           pk16[i][jp] = u32x4{r0[0], r1[0], r0[1], r1[1]};
         }
         if constexpr (TN & 1) pk8[i] = u32x2{w[2 * TN - 2], w[2 * TN - 1]};
+        if constexpr (NOW) {          // the stream's last tile: nothing left to hide its stores under, so block i's go out
+          [&]<int... J>(std::integer_sequence<int, J...>) {   // while block i + 1 is converted
+            ([&] {
+              // the compile-time block index: this loop is unrolled, i is a constant in every copy
+              if (i == 0) chunk_store(std::integral_constant<int, 0 * NIT + J>{});
+              if constexpr (TM > 1) if (i == 1) chunk_store(std::integral_constant<int, 1 * NIT + J>{});
+              if constexpr (TM > 2) if (i == 2) chunk_store(std::integral_constant<int, 2 * NIT + J>{});
+              if constexpr (TM > 3) if (i == 3) chunk_store(std::integral_constant<int, 3 * NIT + J>{});
+              if constexpr (TM > 4) if (i == 4) chunk_store(std::integral_constant<int, 4 * NIT + J>{});
+              if constexpr (TM > 5) if (i == 5) chunk_store(std::integral_constant<int, 5 * NIT + J>{});
+              if constexpr (TM > 6) if (i == 6) chunk_store(std::integral_constant<int, 6 * NIT + J>{});
+              if constexpr (TM > 7) if (i == 7) chunk_store(std::integral_constant<int, 7 * NIT + J>{});
+            }(), ...);
+          }(std::make_integer_sequence<int, NIT>{});
+        }
       }
+      };
+      if (has_next) blocks(std::false_type{});
+      else blocks(std::true_type{});
     }
 #ifdef PP_GEMM_TIMELINE
     ct_conv += __builtin_amdgcn_s_memtime() - cc0;
@@ -751,10 +777,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   rt_loop1 = __builtin_amdgcn_s_memrealtime();
   ct_loop1 = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- the last tile's chunks; the stream's last (unused) K-tile requests must land before the LDS is freed
-  [&]<int... Q>(std::integer_sequence<int, Q...>) {
-    (chunk_store(std::integral_constant<int, Q>{}), ...);
-  }(std::make_integer_sequence<int, ST>{});
+  // ---- the stream's last (unused) K-tile requests must land before the LDS is freed
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef PP_GEMM_TIMELINE
   if ((p.epilogue & (1 << 30)) && lane == 0) {

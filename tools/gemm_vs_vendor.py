@@ -21,7 +21,7 @@ from probpose_pytorch_amd import _lib, ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--inner", type=int, default=10)
-ap.add_argument("--tiles", default="2,3,4,5,6,7,9,10,13,14")
+ap.add_argument("--tiles", default="2,3,4,5,6,7,9,10,13,14,18,19,20")
 ap.add_argument("--shapes", default="", help="comma-separated shape names (default: all)")
 ap.add_argument("--no-vendor", action="store_true")
 args = ap.parse_args()

@@ -4,7 +4,7 @@ set -eo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 # (name M N K tile [resid]): the tiles the round-3 tuner picks, plus the runner-up of the wide-N shapes
-for SHAPE in "qkv_t13 12288 2304 768 13" "qkv_t6 12288 2304 768 6" "proj_t6 12288 768 768 6 resid" "fc1_t9 12288 3072 768 9" "fc1_t7 12288 3072 768 7" "fc2_t6 12288 768 3072 6 resid"; do
+for SHAPE in "qkv_t19 12288 2304 768 19" "qkv_t13 12288 2304 768 13" "proj_t6 12288 768 768 6 resid" "fc1_t20 12288 3072 768 20" "fc1_t18 12288 3072 768 18" "fc1_t7 12288 3072 768 7" "fc2_t6 12288 768 3072 6 resid"; do
   set -- $SHAPE
   NAME=$1; shift
   M=$1; N=$2; K=$3; T=$4; R=${5:-}

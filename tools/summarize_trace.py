@@ -33,11 +33,11 @@ def main(d, out):
     lines = [f"# rocprofv3 kernel trace summary ({os.path.basename(d)})", "",
              f"total kernel time {total / 1e3:.3f} ms over {len(rows)} dispatches", "",
              "| kernel | calls | total us | avg us | % |", "|---|---|---|---|---|"]
-    is_gemm = lambda k: any(t in k for t in ("gemm_kernel", "gemm_persist_kernel", "gemm_duo_kernel"))
+    is_gemm = lambda k: any(t in k for t in ("gemm_kernel", "gemm_persist_kernel", "gemm_duo_kernel", "gemm_quad_stream_kernel"))
     gn = sum(n for k, (n, t) in per.items() if is_gemm(k))
     gt = sum(t for k, (n, t) in per.items() if is_gemm(k))
     if gn:   # the figure bench.py's roofline.avg_launch_us is compared with
-        lines.append(f"| **`pp::gemm_kernel` / `gemm_persist_kernel` / `gemm_duo_kernel`, all instantiations** | {gn} | {gt:.1f} | **{gt / gn:.2f}** | {100 * gt / total:.1f} |")
+        lines.append(f"| **`pp::gemm_kernel` / `gemm_persist_kernel` / `gemm_duo_kernel` / `gemm_quad_stream_kernel`, all instantiations** | {gn} | {gt:.1f} | **{gt / gn:.2f}** | {100 * gt / total:.1f} |")
     for k, (n, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"| `{k}` | {n} | {t:.1f} | {t / n:.2f} | {100 * t / total:.1f} |")
     lines += ["", "## per launch geometry", "", "| kernel | grid | wg | vgpr | lds | calls | avg us |", "|---|---|---|---|---|---|---|"]
