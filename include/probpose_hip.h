@@ -161,7 +161,13 @@ typedef struct pp_gemm_args {
                                    13 = persistent 192x192 stream (one workgroup per CU walks its tiles as one stream of
                                    K-tiles, the next tile's first K-tiles land under the epilogue; plain bf16 -> bf16
                                    layers with bias / GELU / ReLU, e.g. qkv and fc1).
-                                   11, 12: round-2 experiments, removed (refused). */
+                                   18 / 19 / 20 = four-wave stream forms (pp_gemm_quad.hip): 256x192 / 192x288 / 192x256
+                                   tiles, one wave per SIMD with a 128x96 / 96x144 / 96x128 wave tile, one workgroup per CU
+                                   walking its tiles as one stream of 32-deep K-tiles, a finished tile's rows stored from
+                                   the next tile's K-loop; plain bf16 -> bf16 layers with bias / GELU / ReLU (and the
+                                   head-major qkv layout), M and N whole numbers of tiles, K >= 512 (qkv, fc1).
+                                   11, 12: round-2 experiments, removed (refused); 15 - 17: the per-launch four-wave forms,
+                                   lab builds only (refused by the shipped library). */
   float out_scale;              /* PP_EPI_OUT_FP8: 1 / (scale of the fp8 output tensor) */
   int splitk;                   /* 0 / 1 = off.  S > 1: the launch computes S partial products per batch entry, split s
                                    over the K range [s * Kd, (s + 1) * Kd) (Kd = the PER-SPLIT depth): operands advance
