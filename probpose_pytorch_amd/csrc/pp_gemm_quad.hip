@@ -716,8 +716,25 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
         return (unsigned)(((size_t)hh * p.M * p.hm_HW + d) * 2);
       };
       const int lane_col = (fq & 1) ? 16 + (fq - 1) * 4 : fq * 4;
+      // ROWPAIR (TN a multiple of 4): what a store costs is the number of 128-byte lines it touches (~4.5 cycles per line
+      // and CU, a half-written line like a whole one: tools/ubench/store_bw.hip), and 16 rows x 64 B is 16 lines per KiB.
+      // Neighbouring rows (lanes frow, frow ^ 1) therefore trade chunks so that one store holds 128 contiguous bytes of 8
+      // rows: for the column-pair pair (2 pp, 2 pp + 1), store X carries the even row -- pair 2 pp from the even lane, pair
+      // 2 pp + 1 from the odd lane -- and store Y the odd row.  192 x 256 tiles: every such 128 bytes is one aligned line.
+      constexpr bool ROWPAIR = TN % 4 == 0;
+      if constexpr (ROWPAIR) {
+        const unsigned ld2 = (unsigned)ld_out * 2u;
+        const unsigned row_even = row0 - (unsigned)(frow & 1) * ld2;
 #pragma unroll
-      for (int jp = 0; jp < NPAIR; ++jp) cp[jp] = row0 + col_off(n0 + wn * 16 * TN + jp * 32 + lane_col);
+        for (int pp = 0; pp < NPAIR / 2; ++pp) {
+          const unsigned col = col_off(n0 + wn * 16 * TN + (2 * pp + (frow & 1)) * 32 + lane_col);
+          cp[2 * pp] = row_even + col;
+          cp[2 * pp + 1] = row_even + ld2 + col;
+        }
+      } else {
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) cp[jp] = row0 + col_off(n0 + wn * 16 * TN + jp * 32 + lane_col);
+      }
       if constexpr (TN & 1) cp[NPAIR] = row0 + col_off(n0 + wn * 16 * TN + (TN - 1) * 16 + fq * 4);
       auto blocks = [&](auto now_c) __attribute__((always_inline)) {
       constexpr bool NOW = decltype(now_c)::value;
@@ -745,6 +762,24 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
           const auto r0 = __builtin_amdgcn_permlane16_swap(w[4 * jp], w[4 * jp + 2], false, false);
           const auto r1 = __builtin_amdgcn_permlane16_swap(w[4 * jp + 1], w[4 * jp + 3], false, false);
           pk16[i][jp] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        }
+        if constexpr (ROWPAIR) {
+          const bool odd = (frow & 1) != 0;
+#pragma unroll
+          for (int pp = 0; pp < NPAIR / 2; ++pp) {
+            const u32x4 P = pk16[i][2 * pp], Q = pk16[i][2 * pp + 1];
+            u32x4 S;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned give = odd ? P[e] : Q[e];          // what lane frow ^ 1 needs from this one
+              S[e] = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              pk16[i][2 * pp][e] = odd ? S[e] : P[e];            // store X: the even row
+              pk16[i][2 * pp + 1][e] = odd ? Q[e] : S[e];        // store Y: the odd row
+            }
+          }
         }
         if constexpr (TN & 1) pk8[i] = u32x2{w[2 * TN - 2], w[2 * TN - 1]};
         if constexpr (NOW) {          // the stream's last tile: nothing left to hide its stores under, so block i's go out
