@@ -324,6 +324,41 @@ __global__ __launch_bounds__(256, 3) void attention_mfma_kernel(const bf16_t *__
       continue;
     }
     bf16_t *orow = out + ((size_t)b * N + q) * C + h * AT_HD;
+    if constexpr (G::DT == 4 && FULL) {
+      // head_dim 64: a head's output row is ONE aligned 128-byte line.  What a store costs is the lines it touches
+      // (tools/ubench/store_bw.hip), and 8 bytes per lane is 16 rows x 32 B = 16 lines per 512 B.  As in
+      // gemm_quad_stream_kernel: two v_permlane16_swap_b32 per pair of dim tiles give a lane 8 consecutive dims, rows
+      // lrow / lrow ^ 1 then trade halves by DPP so that one 16-byte store holds the whole line of 8 rows: 2 stores of
+      // 8 lines per query tile instead of 4 stores of 16.
+      unsigned w[8];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf16x2(oacc[dt][t][0] * inv_l[t], oacc[dt][t][1] * inv_l[t]);
+        w[2 * dt + 1] = pack_bf16x2(oacc[dt][t][2] * inv_l[t], oacc[dt][t][3] * inv_l[t]);
+      }
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 PQ[2];
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {       // dim tiles 2 jp, 2 jp + 1: even g -> dims 4 g .. + 7 of tile 2 jp, odd g -> of tile 2 jp + 1
+        const auto r0 = __builtin_amdgcn_permlane16_swap(w[4 * jp], w[4 * jp + 2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(w[4 * jp + 1], w[4 * jp + 3], false, false);
+        PQ[jp] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+      const bool odd = (lrow & 1) != 0;
+      u32x4 X, Y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned give = odd ? PQ[0][e] : PQ[1][e];                                   // what lane lrow ^ 1 needs
+        const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+        X[e] = odd ? got : PQ[0][e];       // the even row: dims 0 .. 31 from the even lane, 32 .. 63 from the odd lane
+        Y[e] = odd ? PQ[1][e] : got;       // the odd row
+      }
+      const int lane_dim = ((g & 1) ? 16 + (g - 1) * 4 : g * 4) + (odd ? 32 : 0);
+      bf16_t *even_row = out + ((size_t)b * N + (q & ~1)) * C + h * AT_HD + lane_dim;
+      *reinterpret_cast<u32x4 *>(even_row) = X;
+      *reinterpret_cast<u32x4 *>(even_row + C) = Y;
+      continue;
+    }
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) {
       uint2 pk;
@@ -608,7 +643,8 @@ static int attention_dispatch(const void *qkv, void *out, int B, int N, int head
       const dim3 grid(B * heads), block(256);
       const bf16_t *qp = (const bf16_t *)qkv;
       bf16_t *op = (bf16_t *)out;
-      const bool full = N == AT_NMAX;
+      // FULL at head_dim 64 stores whole 128-byte output lines, 16 bytes per lane: needs a 16-byte aligned `out`
+      const bool full = N == AT_NMAX && (hd != 64 || fp8_inv_scale > 0.f || ((uintptr_t)out & 15) == 0);
       if (hd == 64 && full)
         hipLaunchKernelGGL((attention_mfma_kernel<64, true>), grid, block, AttGeom<64>::LDS, s, qp, op, N, heads, scale_log2e, fp8_inv_scale);
       else if (hd == 64)
