@@ -61,7 +61,8 @@ def test_product_path_fails_loudly_without_gpu():
 def test_gemm_argument_validation_without_gpu(built_lib):
     """pp_gemm's host-side refusals come before any launch (no GPU needed): retired tile selectors, the fused final
     layer on a C pointer that cannot take the LDS epilogue (it would otherwise fall through to the direct store loop
-    and write 256-channel rows into the [B,K,HW] heat buffer), persistent tile on a residual layer, decode flags."""
+    and write 256-channel rows into the [B,K,HW] heat buffer), persistent tile on a residual layer, the four-wave forms
+    on what they do not serve, decode flags."""
     import ctypes as C
     from probpose_pytorch_amd import _lib
     a = _lib.GemmArgs()
@@ -70,6 +71,18 @@ def test_gemm_argument_validation_without_gpu(built_lib):
     for tile in (11, 12, 21, -1):
         a.tile = tile
         assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tile" in built_lib.pp_last_error()
+    # the four-wave forms: 15 - 17 (per launch) exist in lab builds only; the stream forms 18 - 20 take whole tiles, K >= 512, bf16
+    a.tile = 16
+    assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"lab builds" in built_lib.pp_last_error()
+    a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc = 300, 576, 512, 512, 512, 576
+    for tile in (18, 19, 20):
+        a.tile = tile
+        assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tiles 18 - 20" in built_lib.pp_last_error()
+    a.M, a.Kd, a.lda, a.ldw, a.tile = 768, 256, 256, 256, 19
+    assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"K >= 512" in built_lib.pp_last_error()
+    a.Kd, a.lda, a.ldw, a.epilogue, a.residual = 512, 512, 512, _lib.EPI_RESIDUAL | _lib.EPI_OUT_F32, 0x3000
+    assert built_lib.pp_gemm(C.byref(a), None) != 0 and b"tiles 15 - 20" in built_lib.pp_last_error()
+    a.M, a.N, a.Kd, a.lda, a.ldw, a.ldc, a.epilogue, a.residual = 192, 256, 256, 256, 256, 256, 0, None
     a.tile, a.epilogue = 9, _lib.EPI_FUSE_FINAL | _lib.EPI_RELU
     a.final_w, a.final_b, a.hm_K, a.hm_HW, a.hm_temperature = 0x4000, 0x5000, 17, 3072, 0.5
     a.C = 0x3004                                           # 4-byte aligned only: no LDS epilogue possible
