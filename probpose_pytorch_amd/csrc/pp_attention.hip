@@ -576,8 +576,8 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16
     l += __shfl_xor(l, 32, 64);
     const float inv_l = 1.0f / l;
     const int q = q0 + t * 16 + lrow;
-    if (q >= N) continue;
     if (fp8_inv_scale > 0.f) {
+      if (q >= N) continue;
       unsigned char *orow8 = reinterpret_cast<unsigned char *>(out) + ((size_t)b * N + q) * C + h * HD;
       const float sc = inv_l * fp8_inv_scale;
 #pragma unroll
@@ -586,13 +586,60 @@ __global__ __launch_bounds__(NW * 64, 3) void attention_stream_kernel(const bf16
             att_pack_fp8x4(oacc[dt][t][0] * sc, oacc[dt][t][1] * sc, oacc[dt][t][2] * sc, oacc[dt][t][3] * sc);
       continue;
     }
-    bf16_t *orow = out + ((size_t)b * N + q) * C + h * HD;
+    if constexpr (G::DT < 4) {      // head_dim 32: one pair of dim tiles only; the 8-byte form stays (the wide form returned
+      if (q >= N) continue;         // NaN rows at head_dim 32 in this kernel -- rows q with (q & 0x14) == 0x10 -- for a reason not
+      bf16_t *orow = out + ((size_t)b * N + q) * C + h * HD;      // found in the ISA; head_dim 64 / 80 are bit-identical to this form)
 #pragma unroll
-    for (int dt = 0; dt < G::DT; ++dt) {
-      uint2 pk;
-      pk.x = pack_bf16x2(oacc[dt][t][0] * inv_l, oacc[dt][t][1] * inv_l);
-      pk.y = pack_bf16x2(oacc[dt][t][2] * inv_l, oacc[dt][t][3] * inv_l);
-      *reinterpret_cast<uint2 *>(orow + dt * 16 + g * 4) = pk;
+      for (int dt = 0; dt < G::DT; ++dt) {
+        uint2 pk;
+        pk.x = pack_bf16x2(oacc[dt][t][0] * inv_l, oacc[dt][t][1] * inv_l);
+        pk.y = pack_bf16x2(oacc[dt][t][2] * inv_l, oacc[dt][t][3] * inv_l);
+        *reinterpret_cast<uint2 *>(orow + dt * 16 + g * 4) = pk;
+      }
+      continue;
+    }
+    // bf16 rows leave 16 bytes per lane.  What a store costs is the 128-byte lines it touches (tools/ubench/store_bw.hip):
+    // 8 bytes per lane is 16 rows x 32 B = 16 lines per 512 B.  Two v_permlane16_swap_b32 per pair of dim tiles give a lane
+    // 8 consecutive dims (64 B per row and store); where there are two pairs, rows lrow / lrow ^ 1 trade one each by DPP
+    // so that a store holds 128 contiguous bytes of 8 rows.  Every lane takes part in the exchanges (rows past N hold
+    // garbage and are not stored): q is a lane's own row, the exchanged chunks belong to rows q & ~1 and q | 1.
+    {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      constexpr int NP = G::DT / 2;                  // pairs of dim tiles
+      unsigned w[2 * G::DT];
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt) {
+        w[2 * dt] = pack_bf16x2(oacc[dt][t][0] * inv_l, oacc[dt][t][1] * inv_l);
+        w[2 * dt + 1] = pack_bf16x2(oacc[dt][t][2] * inv_l, oacc[dt][t][3] * inv_l);
+      }
+      u32x4 ch[NP > 0 ? NP : 1];
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {       // even g: dims 4 g .. + 7 of tile 2 jp; odd g: dims 4 (g - 1) .. + 7 of tile 2 jp + 1
+        const auto r0 = __builtin_amdgcn_permlane16_swap(w[4 * jp], w[4 * jp + 2], false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(w[4 * jp + 1], w[4 * jp + 3], false, false);
+        ch[jp] = u32x4{r0[0], r1[0], r0[1], r1[1]};
+      }
+      const bool odd = (lrow & 1) != 0;
+      const int lane_dim = (g & 1) ? 16 + (g - 1) * 4 : g * 4;
+      bf16_t *head0 = out + (size_t)b * N * C + h * HD;
+#pragma unroll
+      for (int pp = 0; pp < NP / 2; ++pp) {
+        u32x4 X, Y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned give = odd ? ch[2 * pp][e] : ch[2 * pp + 1][e];
+          const unsigned got = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+          X[e] = odd ? got : ch[2 * pp][e];
+          Y[e] = odd ? ch[2 * pp + 1][e] : got;
+        }
+        const int dim = (2 * pp + (odd ? 1 : 0)) * 32 + lane_dim;
+        if ((q & ~1) < N) *reinterpret_cast<u32x4 *>(head0 + (size_t)(q & ~1) * C + dim) = X;
+        if ((q | 1) < N) *reinterpret_cast<u32x4 *>(head0 + (size_t)(q | 1) * C + dim) = Y;
+      }
+      if (q < N) {
+        if constexpr (NP & 1) *reinterpret_cast<u32x4 *>(head0 + (size_t)q * C + (NP - 1) * 32 + lane_dim) = ch[NP - 1];
+        if constexpr (G::DT & 1) *reinterpret_cast<uint2 *>(head0 + (size_t)q * C + (G::DT - 1) * 16 + g * 4) = uint2{w[2 * G::DT - 2], w[2 * G::DT - 1]};
+      }
     }
   }
 }
@@ -656,7 +703,8 @@ static int attention_dispatch(const void *qkv, void *out, int B, int N, int head
       PP_CHECK_LAUNCH("attention_mfma_kernel");
       return 0;
     }
-    if ((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 &&
+    if ((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 &&
+        ((uintptr_t)out & (fp8_inv_scale > 0.f ? 7 : 15)) == 0 &&          // bf16 rows leave 16 bytes per lane
         ((size_t)B * heads + 8) * ((N + 127) / 128) < (1ull << 31)) {
       if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, fp8_inv_scale, s);
       else if (hd == 64) launch_stream<64>(qkv, out, B, N, heads, fp8_inv_scale, s);
@@ -689,7 +737,7 @@ extern "C" int pp_attention_headmajor(const void *qkv, void *out, int B, int N, 
   PP_REQUIRE(B >= 0 && N > 0 && heads > 0 && hd > 0, "pp_attention_headmajor: bad shape");
   if (B == 0) return 0;
   PP_REQUIRE(qkv && out, "pp_attention_headmajor: null pointer");
-  PP_REQUIRE((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0,
+  PP_REQUIRE((hd == 32 || hd == 64 || hd == 80) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0,
              "pp_attention_headmajor: head_dim 32 / 64 / 80, qkv 16-byte aligned (got head_dim %d)", hd);
   hipStream_t s = (hipStream_t)stream;
   if (hd == 80) launch_stream<80>(qkv, out, B, N, heads, 0.f, s, 1);

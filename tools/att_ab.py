@@ -16,7 +16,9 @@ for L in libs.values():
     L.pp_attention.restype = C.c_int
     L.pp_attention.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-for name, B, N, heads, hd in [("vit_b bs64", 64, 192, 12, 64), ("vit_l bs256", 256, 192, 16, 64)]:
+for name, B, N, heads, hd in [("vit_b bs64", 64, 192, 12, 64), ("vit_l bs256", 256, 192, 16, 64), ("vit_s bs64 (hd 32)", 64, 192, 12, 32),
+                              ("vit_h 384x288 bs128 (hd 80, streaming)", 128, 432, 16, 80), ("vit_l 384x288 bs64 (hd 64, streaming)", 64, 432, 16, 64),
+                              ("ragged N = 433, hd 80", 8, 433, 16, 80), ("ragged N = 200, hd 32", 2, 200, 2, 32), ("ragged N = 50, hd 64", 1, 50, 4, 64)]:
     Cc = heads * hd
     qkv = torch.randn((B * N, 3 * Cc), device="cuda").to(torch.bfloat16)
     outs = {k: torch.empty((B * N, Cc), dtype=torch.bfloat16, device="cuda") for k in libs}
@@ -33,4 +35,8 @@ for name, B, N, heads, hd in [("vit_b bs64", 64, 192, 12, 64), ("vit_l bs256", 2
             e.synchronize()
             times[k].append(s.elapsed_time(e) / 20 * 1e3)
     same = torch.equal(*outs.values())
+    if not same:
+        a, b_ = list(outs.values())
+        bad = (a != b_).nonzero()
+        print("   differing elements:", bad.shape[0], "first", bad[:6].tolist(), "rows", sorted(set(bad[:, 0].tolist()))[:12], "cols", sorted(set(bad[:, 1].tolist()))[:24])
     print(name, {k: round(sorted(v)[len(v) // 2], 2) for k, v in times.items()}, "us; outputs identical:", same)
