@@ -690,9 +690,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
     const unsigned long long cc0 = __builtin_amdgcn_s_memtime();
 #endif
     // -- the finished tile, per wave, no LDS, no barrier: accumulators -> packed 16-byte chunks in registers; they leave from
-    // the next tile's first NSI K-tiles, two or three per K-tile, so that the chip's 256 CUs -- which all finish their tiles
-    // within the same microsecond -- never write in a burst (stored at once, the 28 MB of a qkv round filled the write path
-    // and every store waited for it: 4.9 us per tile, measured).
+    // the next tile's first NSI K-tiles, two or three per K-tile (3 % fewer cycles per workgroup than storing them here;
+    // a real store takes ~236 cycles out of its wave wherever it is issued: DESIGN 4.1).
     // A lane (frow, fq) owns 4 consecutive columns of row frow in every 16 x 16 MFMA tile.  Two v_permlane16_swap_b32 per
     // pair of column tiles (j, j + 1) hand every lane 8 consecutive columns instead: even fq gets columns 4 fq .. 4 fq + 7 of
     // tile j (its own 4 + those of lane fq + 1), odd fq columns 4 (fq - 1) .. + 7 of tile j + 1: one 16-byte store per lane,
