@@ -462,6 +462,13 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   constexpr int NSI = 12;                               // the K-tiles of the NEXT tile that carry them (2 - 3 each)
   constexpr int SLOT0 = 8 - PMAX;                       // pieces sit in slots SLOT0 .. 7
   constexpr int P2 = 2 * PMAX;
+  // PERM (the 192 x 288 form): a wave's 144 columns start at byte 0 / 32 / 64 / 96 of a 128-byte line depending on the
+  // tile's parity and the wave column, so its 128-byte store segments would straddle lines in three cases of four.  The
+  // 18 column tiles (16 columns each) of the tile are therefore dealt out by tile parity: wave column wn takes the eight
+  // tiles from the first line-aligned one -- tiles 8 wn .. 8 wn + 7 of an even tile, 2 + 8 wn .. 9 + 8 wn of an odd one
+  // (n0 * 2 bytes = 576 tn is 64 past a line there) -- as its column tiles 0 .. 7, and one of the two left-over tiles
+  // (16 + wn, or wn) as its tile 8.  Only the W rows a DMA piece fetches, the bias slice and the store offsets know.
+  constexpr bool PERM = TN == 9;
   static_assert(PTA % 4 == 0 && PMAX <= 8 && PMAX - 2 >= KA, "piece layout");
   static_assert(P2 + 2 * ((ST + NSI - 1) / NSI) + 1 <= 63, "vmcnt is a 6-bit counter");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -504,19 +511,32 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   const int lchunk_off = (pchunk ^ perm_p) * 16;
   const int has_last = (PREM == 0 || wave < PREM) ? 1 : 0;
   const int last_k = has_last ? PMAX - 1 : PMAX - 2;      // a wave without a piece PMAX - 1 re-issues piece PMAX - 2 in its place
-  unsigned off[PMAX];
+  auto col_tile = [](int parity, int wn_, int j) constexpr {       // PERM: global column tile of wave column wn_'s tile j
+    return j < 8 ? (parity ? 2 : 0) + 8 * wn_ + j : (parity ? wn_ : 16 + wn_);
+  };
+  unsigned off[PMAX], off_odd[PERM ? PMAX : 1];             // off_odd: the W pieces of an odd tile (PERM)
 #pragma unroll
   for (int k = 0; k < PMAX; ++k) {
     const int kk = (k == PMAX - 1) ? last_k : k;          // wave-uniform
     const int q = wave + 4 * kk;
-    off[k] = (unsigned)((k < KA ? (q * 16 + prow) * p.lda : ((q - PTA) * 16 + prow) * p.ldw) * 2 + lchunk_off);
+    if constexpr (PERM) {
+      const int lp = q - PTA;                             // LDS column tile of a W piece: wave column lp / 9, its tile lp % 9
+      const int ge = col_tile(0, lp / TN, lp % TN), go = col_tile(1, lp / TN, lp % TN);
+      off[k] = (unsigned)((k < KA ? (q * 16 + prow) * p.lda : (ge * 16 + prow) * p.ldw) * 2 + lchunk_off);
+      off_odd[k] = (unsigned)((k < KA ? (q * 16 + prow) * p.lda : (go * 16 + prow) * p.ldw) * 2 + lchunk_off);
+    } else {
+      off[k] = (unsigned)((k < KA ? (q * 16 + prow) * p.lda : ((q - PTA) * 16 + prow) * p.ldw) * 2 + lchunk_off);
+    }
   }
+  int st_par = 0;                                           // parity of the tile being staged (PERM)
   const unsigned lds0 = lds_offset_of(smem);
   unsigned st_lds = 0;
   unsigned long long st_A = 0, st_W = 0;
   auto piece = [&](auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
-    return QuadPiece{off[k], k < KA ? st_A : st_W, st_lds + (k == PMAX - 1 ? last_k : k) * 4096};
+    unsigned o = off[k];
+    if constexpr (PERM && k >= KA) o = st_par ? off_odd[k] : off[k];
+    return QuadPiece{o, k < KA ? st_A : st_W, st_lds + (k == PMAX - 1 ? last_k : k) * 4096};
   };
   auto stage_slot = [&](auto bc) __attribute__((always_inline)) {   // slot B carries piece B - SLOT0 of every wave
     constexpr int B = decltype(bc)::value;
@@ -530,8 +550,13 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   const char *bias_src = (epi & PP_EPI_BIAS) ? (const char *)p.bias : p.W;      // no bias: any readable bytes, never used
   const int bias_cols = (epi & PP_EPI_BIAS) ? p.N : 4;
   auto bias_piece = [&](int tn, int par) __attribute__((always_inline)) {
-    const int c0 = tn * BN + wn * 16 * TN;
-    const int c = min(c0 + lane * 4, bias_cols - 4);
+    int c0 = tn * BN + wn * 16 * TN;
+    int c = min(c0 + lane * 4, bias_cols - 4);
+    if constexpr (PERM) {       // floats 0 .. 127: the wave's eight grouped column tiles; 128 .. 143: its left-over tile
+      const int g0 = col_tile(tn & 1, wn, 0), g8 = col_tile(tn & 1, wn, 8);
+      c0 = tn * BN + (lane < 32 ? g0 * 16 + lane * 4 : g8 * 16 + (lane & 3) * 4);
+      c = min(c0, bias_cols - 4);
+    }
     return QuadPiece{(unsigned)(c * 4), uniform64(bias_src),
                      (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + BIAS_OFF + par * 4096 + wave * 1024))};
   };
@@ -611,6 +636,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   tile_base(tm, tn, curA, curW);
   int par = 0;
   glds_piece(bias_piece(tn, par));
+  st_par = tn & 1;
 #pragma unroll
   for (int s_ = 0; s_ < STAGES; ++s_) {
     st_lds = __builtin_amdgcn_readfirstlane(lds0 + s_ * STAGE_BYTES + wave * 1024);
@@ -658,6 +684,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
       st_lds = __builtin_amdgcn_readfirstlane(lds0 + b * STAGE_BYTES + wave * 1024);
       st_A = (wrap ? nxtA : curA) + (unsigned)(k2 * RB);
       st_W = (wrap ? nxtW : curW) + (unsigned)(k2 * RB);
+      st_par = (wrap ? ntn : tn) & 1;
     };
     // -- iterations 0 .. NSI + 1, unrolled: each carries its share of the previous tile's chunk stores (compile-time
     // registers) and waits for 2 PMAX + what the two iterations before it issued besides their pieces
@@ -720,13 +747,14 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
       // Neighbouring rows (lanes frow, frow ^ 1) therefore trade chunks so that one store holds 128 contiguous bytes of 8
       // rows: for the column-pair pair (2 pp, 2 pp + 1), store X carries the even row -- pair 2 pp from the even lane, pair
       // 2 pp + 1 from the odd lane -- and store Y the odd row.  192 x 256 tiles: every such 128 bytes is one aligned line.
-      constexpr bool ROWPAIR = TN % 4 == 0;
+      constexpr bool ROWPAIR = TN % 4 == 0 || PERM;
+      const int wcol0 = PERM ? col_tile(tn & 1, wn, 0) * 16 : wn * 16 * TN;      // the wave's first (grouped) column in the tile
       if constexpr (ROWPAIR) {
         const unsigned ld2 = (unsigned)ld_out * 2u;
         const unsigned row_even = row0 - (unsigned)(frow & 1) * ld2;
 #pragma unroll
         for (int pp = 0; pp < NPAIR / 2; ++pp) {
-          const unsigned col = col_off(n0 + wn * 16 * TN + (2 * pp + (frow & 1)) * 32 + lane_col);
+          const unsigned col = col_off(n0 + wcol0 + (2 * pp + (frow & 1)) * 32 + lane_col);
           cp[2 * pp] = row_even + col;
           cp[2 * pp + 1] = row_even + ld2 + col;
         }
@@ -734,7 +762,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
 #pragma unroll
         for (int jp = 0; jp < NPAIR; ++jp) cp[jp] = row0 + col_off(n0 + wn * 16 * TN + jp * 32 + lane_col);
       }
-      if constexpr (TN & 1) cp[NPAIR] = row0 + col_off(n0 + wn * 16 * TN + (TN - 1) * 16 + fq * 4);
+      if constexpr (TN & 1)
+        cp[NPAIR] = row0 + col_off(n0 + (PERM ? col_tile(tn & 1, wn, 8) * 16 : wn * 16 * TN + (TN - 1) * 16) + fq * 4);
       auto blocks = [&](auto now_c) __attribute__((always_inline)) {
       constexpr bool NOW = decltype(now_c)::value;
 #pragma unroll
