@@ -468,7 +468,9 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   // tiles from the first line-aligned one -- tiles 8 wn .. 8 wn + 7 of an even tile, 2 + 8 wn .. 9 + 8 wn of an odd one
   // (n0 * 2 bytes = 576 tn is 64 past a line there) -- as its column tiles 0 .. 7, and one of the two left-over tiles
   // (16 + wn, or wn) as its tile 8.  Only the W rows a DMA piece fetches, the bias slice and the store offsets know.
-  constexpr bool PERM = TN == 9;
+  // The 256 x 192 form (TN = 6: 192-byte wave segments, tiles always line-aligned) has the same problem in wave column 1
+  // only: it takes the tile's last four column tiles as its tiles 0 - 3 and tiles 6, 7 as its 4, 5.
+  constexpr bool PERM = TN == 9 || TN == 6;
   static_assert(PTA % 4 == 0 && PMAX <= 8 && PMAX - 2 >= KA, "piece layout");
   static_assert(P2 + 2 * ((ST + NSI - 1) / NSI) + 1 <= 63, "vmcnt is a 6-bit counter");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   const int has_last = (PREM == 0 || wave < PREM) ? 1 : 0;
   const int last_k = has_last ? PMAX - 1 : PMAX - 2;      // a wave without a piece PMAX - 1 re-issues piece PMAX - 2 in its place
   auto col_tile = [](int parity, int wn_, int j) constexpr {       // PERM: global column tile of wave column wn_'s tile j
+    if (TN == 6) return wn_ == 0 ? j : (j < 4 ? 8 + j : 2 + j);
     return j < 8 ? (parity ? 2 : 0) + 8 * wn_ + j : (parity ? wn_ : 16 + wn_);
   };
   unsigned off[PMAX], off_odd[PERM ? PMAX : 1];             // off_odd: the W pieces of an odd tile (PERM)
@@ -552,9 +555,12 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
   auto bias_piece = [&](int tn, int par) __attribute__((always_inline)) {
     int c0 = tn * BN + wn * 16 * TN;
     int c = min(c0 + lane * 4, bias_cols - 4);
-    if constexpr (PERM) {       // floats 0 .. 127: the wave's eight grouped column tiles; 128 .. 143: its left-over tile
-      const int g0 = col_tile(tn & 1, wn, 0), g8 = col_tile(tn & 1, wn, 8);
-      c0 = tn * BN + (lane < 32 ? g0 * 16 + lane * 4 : g8 * 16 + (lane & 3) * 4);
+    if constexpr (PERM) {       // float 16 j + e of the slot: column e of the wave's column tile j
+      const int lt = min(lane >> 2, TN - 1);
+      int g = col_tile(tn & 1, wn, 0) + lt;                       // tiles 0 .. 7 (TN 9) / 0 .. 3 (TN 6) are consecutive
+      if (TN == 9 && lt == 8) g = col_tile(tn & 1, wn, 8);
+      if (TN == 6 && lt >= 4) g = col_tile(0, wn, 4) + lt - 4;
+      c0 = tn * BN + g * 16 + (lane & 3) * 4;
       c = min(c0, bias_cols - 4);
     }
     return QuadPiece{(unsigned)(c * 4), uniform64(bias_src),
@@ -749,6 +755,8 @@ __global__ __launch_bounds__(256, 1) void gemm_quad_stream_kernel(GemmParams p, 
       // 2 pp + 1 from the odd lane -- and store Y the odd row.  192 x 256 tiles: every such 128 bytes is one aligned line.
       constexpr bool ROWPAIR = TN % 4 == 0 || PERM;
       const int wcol0 = PERM ? col_tile(tn & 1, wn, 0) * 16 : wn * 16 * TN;      // the wave's first (grouped) column in the tile
+      if constexpr (ROWPAIR && (NPAIR & 1))      // an unpaired last pair of column tiles (TN 6: tiles 4, 5): 64-byte segments
+        cp[NPAIR - 1] = row0 + col_off(n0 + (PERM ? col_tile(tn & 1, wn, NPAIR * 2 - 2) * 16 : wn * 16 * TN + (NPAIR - 1) * 32) + lane_col);
       if constexpr (ROWPAIR) {
         const unsigned ld2 = (unsigned)ld_out * 2u;
         const unsigned row_even = row0 - (unsigned)(frow & 1) * ld2;
