@@ -294,6 +294,22 @@ def test_attention(ops, dtype, B, N, heads, hd):
     torch.testing.assert_close(out.double(), ref, **tol)
 
 
+@pytest.mark.parametrize("B,N,heads,hd", [(2, 192, 12, 64), (2, 432, 2, 80), (1, 577, 2, 64), (1, 300, 2, 32)])
+def test_attention_output_only_8_byte_aligned(ops, B, N, heads, hd):
+    """The bf16 kernels store whole output lines 16 bytes per lane when `out` is 16-byte aligned; an `out` that is only
+    8-byte aligned takes the narrower forms: same numbers either way."""
+    C = heads * hd
+    qkv = _rand((B * N, 3 * C), torch.bfloat16, 1)
+    aligned = torch.empty((B * N, C), dtype=torch.bfloat16, device="cuda")
+    ops.attention(qkv, aligned, B, N, heads, hd)
+    buf = torch.full((B * N * C + 8,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    shifted = buf[4:4 + B * N * C].view(B * N, C)
+    assert shifted.data_ptr() % 16 == 8
+    ops.attention(qkv, shifted, B, N, heads, hd)
+    torch.testing.assert_close(shifted.float(), aligned.float(), rtol=2 ** -6, atol=2e-2)
+    assert torch.isnan(buf[:4]).all() and torch.isnan(buf[4 + B * N * C:]).all()       # nothing written outside
+
+
 @pytest.mark.parametrize("tile", [0, 2, 3, 6, 7, 10, 13])
 @pytest.mark.parametrize("B,N,heads,hd", [(2, 432, 16, 80), (3, 192, 12, 32), (1, 50, 4, 64), (2, 433, 4, 80)])
 def test_headmajor_qkv_projection_and_attention(ops, tile, B, N, heads, hd):
